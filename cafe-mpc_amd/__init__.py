@@ -1,0 +1,62 @@
+"""cafe-mpc_amd — MI355X-native Hybrid-Systems DDP solver behind CAFE-MPC's MultiPhaseDDP::solve() surface.
+
+The compute path is libhsddp_hip.so (hand-written HIP for gfx950, C-ABI in include/hsddp.h).  This Python
+layer only marshals descriptors; there is NO CPU fallback: if the HIP library is missing, import of the
+solver fails loudly (`load_hip_library`).  The package directory name contains a hyphen, so it is loaded
+through `__graft_entry__.load_package()` under the module name `cafe_mpc_amd`.
+"""
+import ctypes as _C
+import os as _os
+
+from . import _abi
+from ._abi import Option, mhpc_ddp_setting, Solver, MODEL_WB, MODEL_SRB, MODEL_HKD  # noqa: F401
+from . import problems  # noqa: F401
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+HIP_LIB_PATH = _os.path.join(_HERE, "libhsddp_hip.so")
+_lib = None
+
+
+def load_hip_library():
+    """Load and bind libhsddp_hip.so. Raises (never falls back) if it is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not _os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(f"{HIP_LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                               "There is no CPU fallback for the product path.")
+        lib = _C.CDLL(HIP_LIB_PATH)
+        missing = [s for s in _abi.EXPORTS if not hasattr(lib, s)]
+        if missing:
+            raise RuntimeError(f"libhsddp_hip.so lacks symbols {missing}")
+        _lib = _abi.bind(lib)
+    return _lib
+
+
+class MultiPhaseDDP(Solver):
+    """Drop-in for MultiPhaseDDP<double> (HSDDPSolver/header/MultiPhaseDDP.h:22-93) on the HIP backend.
+
+    set_multiPhaseProblem == constructor (phase descriptors), then set_initial_condition(x0[batch,n]),
+    solve(option, max_cputime_ms), get_actual_cost(), get_dyn_infeasibility(), get_solver_info() ...
+    Each call works on the whole batch of independent problems held by the handle.
+    """
+
+    def __init__(self, phases, batch=1, device=0, **kw):
+        super().__init__(load_hip_library(), phases, batch=batch, device=device, **kw)
+        for i, p in enumerate(phases):
+            self.set_nominal(i, p["Xbar"], p["Ubar"])
+
+    def get_actual_cost(self):
+        return self.info_arrays()["actual_cost"]
+
+    def get_dyn_infeasibility(self):
+        return self.info_arrays()["dyn_feas"]
+
+    def get_path_constraint_violation(self):
+        return self.info_arrays()["max_pconstr"]
+
+    def get_terminal_constraint_violation(self):
+        return self.info_arrays()["max_tconstr"]
+
+    def get_solver_info(self):
+        a = self.info_arrays()
+        return a["n_iters"], a["n_ls_iters"], a["n_reg_iters"], self.solve_time_ms()

@@ -1,0 +1,206 @@
+"""Synthetic Mini-Cheetah problem descriptors for the BASELINE.json configurations.
+
+Host-side counterpart of what MHPCProblem (MHPC/MHPC-Trajopt/MHPCProblem.cpp:88-137, 174-249, 403-601)
+binds into SinglePhase objects, emitted as POD phase descriptors (include/hsddp.h).  Inputs are synthetic
+(no CSV gait file): weights from MHPC/settings/cost_weights_regular.JSON, ReB/AL parameters from
+MHPC/settings/constraint_params_regular.info, limits from MHPCConstraint.{h,cpp}.
+"""
+import ctypes as C
+import numpy as np
+
+from ._abi import PhaseDesc, Reb, Al, MODEL_WB, MODEL_SRB, MODEL_DIMS, DP, IP
+
+QJ_NOM = np.array([0.0, -1.0, 2.0] * 4)            # Loco_TO.cpp:53
+Z_NOM = 0.2183                                      # Loco_TO.cpp:54
+MASS_WB = 8.252                                     # URDF link-mass sum
+
+
+def wb_foot_positions(q, psi=np.pi):
+    """World foot positions (4x3, FL FR HL HR) of the 18-dof model (PinocchioInteface.cpp:17-56 + URDF)."""
+    def rx(a): c, s = np.cos(a), np.sin(a); return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    def ry(a): c, s = np.cos(a), np.sin(a); return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    def rz(a): c, s = np.cos(a), np.sin(a); return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    R = rz(q[3]) @ ry(q[4]) @ rx(q[5])
+    p = np.asarray(q[:3], dtype=float)
+    out = np.zeros((4, 3))
+    for l, (sx, sy) in enumerate([(1, 1), (1, -1), (-1, 1), (-1, -1)]):
+        qa, qh, qk = q[6 + 3 * l: 9 + 3 * l]
+        Ra = R @ rx(qa); pa = p + R @ np.array([sx * 0.19, sy * 0.049, 0])
+        Rh = Ra @ rz(psi) @ ry(qh); ph = pa + Ra @ np.array([0, sy * 0.062, 0])
+        Rk = Rh @ ry(qk); pk = ph + Rh @ np.array([0, 0, -0.209])
+        out[l] = pk + Rk @ np.array([0, 0, -0.195])
+    return out
+
+
+def wb_gravity_comp_torque(q, contact, psi=np.pi):
+    """Quasi-static joint torques tau = -J_leg^T F for stance legs sharing the weight equally (builder-side
+    initial control guess; the reference's tests start from Ubar = 0, testMHPCProblem.cpp:70-76)."""
+    nc = max(1, int(np.sum(contact)))
+    F = np.array([0.0, 0.0, MASS_WB * 9.81 / nc])
+    u = np.zeros(12)
+    e = 1e-6
+    for l in range(4):
+        if not contact[l]:
+            continue
+        for j in range(3):
+            qp = np.array(q, dtype=float); qm = np.array(q, dtype=float)
+            qp[6 + 3 * l + j] += e; qm[6 + 3 * l + j] -= e
+            dp = (wb_foot_positions(qp, psi)[l] - wb_foot_positions(qm, psi)[l]) / (2 * e)
+            u[3 * l + j] = -dp @ F
+    return u
+
+
+class SplitMix64:
+    """splitmix64 -> double in [0,1): the portable PRNG SURVEY 8(d) prescribes for the x0 ensemble."""
+    M = (1 << 64) - 1
+
+    def __init__(self, seed):
+        self.s = seed & self.M
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & self.M
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.M
+        z ^= z >> 31
+        return (z >> 11) * (1.0 / 9007199254740992.0)
+
+
+def wb_nominal_state():
+    return np.concatenate([[0, 0, Z_NOM, 0, 0, 0], QJ_NOM, np.zeros(18)])
+
+
+def wb_ensemble_x0(batch, seed, first=0):
+    """x0 = x_nom + uniform delta: pos 0.02, eul 0.05, qJ 0.1, v 0.1, eul-rate 0.2, qJd 0.5.
+    Problem b draws its 36 numbers from stream position b*36 (so any shard reproduces its own slice)."""
+    amp = np.concatenate([[0.02] * 3, [0.05] * 3, [0.1] * 12, [0.1] * 3, [0.2] * 3, [0.5] * 12])
+    xn = wb_nominal_state()
+    out = np.zeros((batch, 36))
+    rng = SplitMix64(seed)
+    rng.s = (rng.s + (first * 36) * 0x9E3779B97F4A7C15) & SplitMix64.M
+    for b in range(batch):
+        u = np.array([rng.next() for _ in range(36)])
+        out[b] = xn + amp * (2 * u - 1)
+    return out
+
+
+def _set(arr, vals):
+    for i, v in enumerate(vals):
+        arr[i] = v
+
+
+def wb_phase(horizon, dt, t_offset, contact, next_contact, refs, next_model=MODEL_WB, bg_alpha=10.0, shooting=1,
+             ubar_mode="gravity_comp"):
+    """One WB phase descriptor with the shipped 'regular' weights/limits. refs: dict of per-knot arrays."""
+    d = PhaseDesc()
+    d.model, d.horizon, d.dt, d.t_offset = MODEL_WB, horizon, dt, t_offset
+    _set(d.contact, contact); _set(d.next_contact, next_contact)
+    d.next_model, d.shooting, d.BG_alpha = next_model, shooting, bg_alpha
+    # cost_weights_regular.JSON -> [q, r, qf] in loadCostWeights order (MHPCCostUtil.h:21-78)
+    q = [0, 0, 10, 1, 2, 2] + [1.0] * 12 + [2, 2, 2, 1, 2, 2] + [0.01] * 12
+    qf = [0, 0, 1, 1, 1, 1] + [0.5] * 12 + [1.0] * 6 + [0.01] * 12
+    _set(d.q, q); _set(d.r, [0.1] * 12); _set(d.qf, qf)
+    _set(d.w_foot_reg, [20.0, 20.0, 1.0]); _set(d.w_swing_pos, [10.0, 10.0, 10.0]); _set(d.w_swing_vel, [2.0, 2.0, 2.0])
+    d.w_td_vel = 1.0
+    d.c_torque = d.c_joint = d.c_minheight = d.c_grf = 1
+    d.torque_limit = 17.0
+    _set(d.joint_lb, [-1.3, -5.0, -np.pi]); _set(d.joint_ub, [1.3, 5.0, np.pi])
+    d.h_min, d.mu = 0.20, 0.6
+    d.reb_grf = Reb(0.1, 0.1, 0.3); d.reb_torque = Reb(0.1, 0.1, 0.1); d.reb_joint = Reb(0.1, 0.1, 0.1)
+    d.reb_minheight = Reb(0.01, 0.01, 0.1)
+    d.c_touchdown, d.ground_height = 1, 0.0
+    d.al_td = Al(10.0, 0.0, 1e4)
+    bufs = {}
+    n, m, p = MODEL_DIMS[MODEL_WB]
+    for name, w in (("xr", n), ("ur", m), ("yr", p), ("foot_pos", 12), ("foot_vel", 12), ("body_pos", 3)):
+        a = np.ascontiguousarray(refs[name], dtype=np.float64)
+        assert a.shape == (horizon + 1, w), (name, a.shape)
+        bufs[name] = a
+        setattr(d, name, a.ctypes.data_as(DP))
+    rc = np.ascontiguousarray(refs["ref_contact"], dtype=np.int32)
+    assert rc.shape == (horizon + 1, 4)
+    bufs["ref_contact"] = rc
+    d.ref_contact = rc.ctypes.data_as(IP)
+    ubar = np.zeros((horizon, m))
+    if ubar_mode == "gravity_comp":
+        ubar[:] = wb_gravity_comp_torque(bufs["xr"][0, :18], contact)
+    return {"desc": d, "bufs": bufs, "Xbar": bufs["xr"].copy(), "Ubar": ubar}
+
+
+def wb_trot_problem(schedule=((1, 1, 1, 1), (0, 1, 1, 0), (1, 0, 0, 1), (0, 1, 1, 0)), horizons=(50, 50, 50, 50),
+                    dt=0.01, vx=0.5, last_next=(1, 0, 0, 1), swing_height=0.06, ubar_mode="gravity_comp"):
+    """Configs 2/3 of BASELINE.json: WB, 4 contact phases x 50 knots, trot-like."""
+    nph = len(schedule)
+    starts = np.concatenate([[0], np.cumsum(horizons)])
+    nominal_feet = wb_foot_positions(wb_nominal_state()[:18])   # relative to body at origin
+    nominal_feet[:, 2] = 0.0
+
+    def body_x(t):
+        return vx * t
+
+    # foothold of foot f while in stance during phase i: under the nominal foot at mid-phase
+    def foothold(i, f):
+        tm = (starts[i] + 0.5 * horizons[i]) * dt
+        return nominal_feet[f] + np.array([body_x(tm), 0, 0])
+
+    phases = []
+    for i in range(nph):
+        h = horizons[i]
+        nxt = schedule[i + 1] if i + 1 < nph else last_next
+        xr = np.zeros((h + 1, 36)); fp = np.zeros((h + 1, 12)); fv = np.zeros((h + 1, 12)); rc = np.zeros((h + 1, 4), dtype=np.int32)
+        yr = np.zeros((h + 1, 12))
+        for k in range(h + 1):
+            t = (starts[i] + k) * dt
+            xr[k, 0] = body_x(t); xr[k, 2] = Z_NOM; xr[k, 6:18] = QJ_NOM; xr[k, 18] = vx
+            c = schedule[i] if k < h else nxt          # reference lookup at the knot's absolute time
+            rc[k] = c
+            nc = max(1, int(np.sum(c)))
+            for f in range(4):
+                if schedule[i][f]:
+                    fp[k, 3 * f:3 * f + 3] = foothold(i, f)
+                else:
+                    # swing from the previous foothold to the next one over this phase
+                    p0 = foothold(i - 1, f) if i > 0 else foothold(i, f) - np.array([vx * h * dt, 0, 0])
+                    p1 = foothold(i + 1, f) if i + 1 < nph else foothold(i, f) + np.array([vx * h * dt, 0, 0])
+                    s = k / h
+                    fp[k, 3 * f:3 * f + 3] = p0 + (p1 - p0) * s + np.array([0, 0, swing_height * np.sin(np.pi * s)])
+                    fv[k, 3 * f:3 * f + 3] = (p1 - p0) / (h * dt) + np.array([0, 0, swing_height * np.pi / (h * dt) * np.cos(np.pi * s)])
+                if c[f]:
+                    yr[k, 3 * f + 2] = MASS_WB * 9.81 / nc
+        refs = dict(xr=xr, ur=np.zeros((h + 1, 12)), yr=yr, foot_pos=fp, foot_vel=fv, body_pos=xr[:, :3].copy(), ref_contact=rc)
+        phases.append(wb_phase(h, dt, starts[i] * dt, schedule[i], nxt, refs, ubar_mode=ubar_mode))
+    return phases
+
+
+def wb_stance_problem(horizon=50, dt=0.01, contact=(1, 1, 1, 1), ubar_mode="gravity_comp"):
+    """Config 1 of BASELINE.json: WB, one phase N=50, constant stance reference."""
+    h = horizon
+    xn = wb_nominal_state()
+    feet = wb_foot_positions(xn[:18]); feet[:, 2] = 0.0
+    xr = np.tile(xn, (h + 1, 1))
+    rc = np.tile(np.array(contact, dtype=np.int32), (h + 1, 1))
+    nc = max(1, int(np.sum(contact)))
+    yr = np.zeros((h + 1, 12))
+    for f in range(4):
+        if contact[f]:
+            yr[:, 3 * f + 2] = MASS_WB * 9.81 / nc
+    refs = dict(xr=xr, ur=np.zeros((h + 1, 12)), yr=yr, foot_pos=np.tile(feet.reshape(-1), (h + 1, 1)),
+                foot_vel=np.zeros((h + 1, 12)), body_pos=xr[:, :3].copy(), ref_contact=rc)
+    return [wb_phase(h, dt, 0.0, contact, contact, refs, ubar_mode=ubar_mode)]
+
+
+def srb_phase(horizon, dt, t_offset, refs):
+    """SRB tail phase (MHPCProblem.cpp:488-521) with cost_weights_regular.JSON SRB weights."""
+    d = PhaseDesc()
+    d.model, d.horizon, d.dt, d.t_offset = MODEL_SRB, horizon, dt, t_offset
+    d.next_model, d.shooting, d.BG_alpha = -1, 1, 0.0
+    _set(d.q, [0, 0, 10, 1, 2, 2, 2, 2, 2, 1, 2, 2]); _set(d.r, [0.01] * 12); _set(d.qf, [0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1])
+    _set(d.w_foot_reg, [-1, 0, 0]); _set(d.w_swing_pos, [-1, 0, 0]); _set(d.w_swing_vel, [-1, 0, 0]); d.w_td_vel = -1
+    d.c_minheight, d.h_min = 1, 0.18
+    d.reb_minheight = Reb(0.01, 0.01, 0.1)
+    bufs = {}
+    for name, w in (("xr", 12), ("ur", 12), ("foot_pos", 12), ("foot_vel", 12), ("body_pos", 3)):
+        a = np.ascontiguousarray(refs[name], dtype=np.float64); assert a.shape == (horizon + 1, w), (name, a.shape)
+        bufs[name] = a; setattr(d, name, a.ctypes.data_as(DP))
+    rc = np.ascontiguousarray(refs["ref_contact"], dtype=np.int32); bufs["ref_contact"] = rc; d.ref_contact = rc.ctypes.data_as(IP)
+    return {"desc": d, "bufs": bufs, "Xbar": bufs["xr"].copy(), "Ubar": np.zeros((horizon, 12))}

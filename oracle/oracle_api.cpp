@@ -1,0 +1,175 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C-ABI of the CPU restatement: the same hsddp_* entry points
+// as include/hsddp.h (so parity tests drive both backends with one harness) plus model-level
+// oracle_* probes used to pin the restatement against the reference's golden vectors.
+#include "hsddp_oracle.hpp"
+#include <new>
+
+struct hsddp_handle { orc::Solver s; };
+using namespace orc;
+
+extern "C" {
+
+const char* hsddp_backend_name(void) { return "cpu-oracle"; }
+
+int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
+    (void)device;
+    if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
+    hsddp_handle* h = new (std::nothrow) hsddp_handle();
+    if (!h) return HSDDP_ENOMEM;
+    int rc = h->s.create(n_phases, phases, mp, batch);
+    if (rc != HSDDP_OK) { delete h; return rc; }
+    *out = h; return HSDDP_OK;
+}
+void hsddp_destroy(hsddp_handle_t* h) { delete h; }
+
+int oracle_set_threads(hsddp_handle_t* h, int lq_threads, int problem_threads) {
+    h->s.lq_threads = lq_threads > 0 ? lq_threads : 1; h->s.problem_threads = problem_threads > 0 ? problem_threads : 1; return 0;
+}
+
+int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) {
+    if (!h || !x0) return HSDDP_EINVAL;
+    int n0 = h->s.ph[0].n;
+    for (int b = 0; b < h->s.batch; b++) { std::memset(h->s.pb[b].x0, 0, sizeof(h->s.pb[b].x0)); std::memcpy(h->s.pb[b].x0, x0 + (size_t)b * n0, sizeof(double) * n0); }
+    return HSDDP_OK;
+}
+int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per_problem) {
+    if (!h || phase < 0 || phase >= (int)h->s.ph.size()) return HSDDP_EINVAL;
+    const PhaseDef& P = h->s.ph[phase]; size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m;
+    for (int b = 0; b < h->s.batch; b++) {
+        Traj& T = h->s.pb[b].tr[phase];
+        if (Xbar) { const double* s = Xbar + (per_problem ? b * sx : 0); std::copy(s, s + sx, T.Xbar.begin()); std::copy(s, s + sx, T.X.begin()); }
+        if (Ubar) { const double* s = Ubar + (per_problem ? b * su : 0); std::copy(s, s + su, T.Ubar.begin()); std::copy(s, s + su, T.U.begin()); }
+        std::fill(T.K.begin(), T.K.end(), 0.0); std::fill(T.dU.begin(), T.dU.end(), 0.0); std::fill(T.dX.begin(), T.dX.end(), 0.0);
+    }
+    return HSDDP_OK;
+}
+int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_ms) {
+    if (!h || !opt) return HSDDP_EINVAL;
+    h->s.solve(*opt, max_cputime_ms); return HSDDP_OK;
+}
+int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.hybrid_rollout(q, eps, *opt); return 0; }
+int hsddp_compute_cost(hsddp_handle_t* h, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.compute_cost(q, *opt); return 0; }
+int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.LQ_approximation(q, *opt); return 0; }
+int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
+    for (int b = 0; b < h->s.batch; b++) { bool ok = h->s.backward_sweep(h->s.pb[b], reg); if (success) success[b] = ok; }
+    return 0;
+}
+int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) { (void)opt; for (auto& q : h->s.pb) h->s.linear_rollout(q, eps); return 0; }
+int hsddp_update_nominal_trajectory(hsddp_handle_t* h) { for (auto& q : h->s.pb) h->s.update_nominal_trajectory(q); return 0; }
+int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* dV_1, double* dV_2) {
+    for (int b = 0; b < h->s.batch; b++) { dV_1[b] = h->s.pb[b].dV_1; dV_2[b] = h->s.pb[b].dV_2; } return 0;
+}
+int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* feas) { for (int b = 0; b < h->s.batch; b++) feas[b] = h->s.measure_dynamics_feasibility(h->s.pb[b]); return 0; }
+
+int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) {
+    for (int b = 0; b < h->s.batch; b++) {
+        const Problem& q = h->s.pb[b];
+        info[b].actual_cost = q.actual_cost; info[b].dyn_feas = q.feas;
+        info[b].max_tconstr = q.eqn_feas_buffer.empty() ? q.max_tconstr : q.eqn_feas_buffer.back();
+        info[b].max_pconstr = q.ineq_feas_buffer.empty() ? q.max_pconstr : q.ineq_feas_buffer.back();
+        info[b].n_iters = q.iter_; info[b].n_ls_iters = q.ls_iter_total_; info[b].n_reg_iters = q.reg_iter_total_; info[b].status = q.status;
+    }
+    return 0;
+}
+static const std::vector<double>* field_ptr(const PhaseDef& P, const Traj& T, int f, int& count, int& elems) {
+    int n = P.n, m = P.m, p = P.p, h = P.h;
+    switch (f) {
+        case HSDDP_F_X: count = h + 1; elems = n; return &T.X;
+        case HSDDP_F_XBAR: count = h + 1; elems = n; return &T.Xbar;
+        case HSDDP_F_XSIM: count = h + 1; elems = n; return &T.Xsim;
+        case HSDDP_F_DEFECT: count = h + 1; elems = n; return &T.Defect;
+        case HSDDP_F_DX: count = h + 1; elems = n; return &T.dX;
+        case HSDDP_F_G: count = h + 1; elems = n; return &T.G;
+        case HSDDP_F_U: count = h; elems = m; return &T.U;
+        case HSDDP_F_UBAR: count = h; elems = m; return &T.Ubar;
+        case HSDDP_F_DU: count = h; elems = m; return &T.dU;
+        case HSDDP_F_QU: count = h; elems = m; return &T.Qu;
+        case HSDDP_F_Y: count = h; elems = p; return &T.Y;
+        case HSDDP_F_K: count = h; elems = m * n; return &T.K;
+        case HSDDP_F_QUX: count = h; elems = m * n; return &T.Qux;
+        case HSDDP_F_QUU: count = h; elems = m * m; return &T.Quu;
+        case HSDDP_F_A: count = h; elems = n * n; return &T.A;
+        case HSDDP_F_B: count = h; elems = n * m; return &T.B;
+        case HSDDP_F_C: count = h; elems = p * n; return &T.C;
+        case HSDDP_F_D: count = h; elems = p * m; return &T.D;
+        case HSDDP_F_L: count = h; elems = 1; return &T.l;
+        case HSDDP_F_LX: count = h; elems = n; return &T.lx;
+        case HSDDP_F_LU: count = h; elems = m; return &T.lu;
+        case HSDDP_F_LY: count = h; elems = p; return &T.ly;
+        case HSDDP_F_LXX: count = h; elems = n * n; return &T.lxx;
+        case HSDDP_F_LUX: count = h; elems = m * n; return &T.lux;
+        case HSDDP_F_LUU: count = h; elems = m * m; return &T.luu;
+        case HSDDP_F_LYY: count = h; elems = p * p; return &T.lyy;
+        case HSDDP_F_PHIX: count = 1; elems = n; return &T.Phix;
+        case HSDDP_F_PHIXX: count = 1; elems = n * n; return &T.Phixx;
+        case HSDDP_F_H0: count = 1; elems = n * n; return &T.H;
+        case HSDDP_F_PHI: count = 1; elems = 1; return nullptr;
+        default: count = 0; elems = 0; return nullptr;
+    }
+}
+int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) {
+    if (!h || phase < 0 || phase >= (int)h->s.ph.size() || field < 0 || field >= HSDDP_F_COUNT) return HSDDP_EINVAL;
+    field_ptr(h->s.ph[phase], h->s.pb[0].tr[phase], field, *count, *elems); return 0;
+}
+int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
+    if (!h || phase < 0 || phase >= (int)h->s.ph.size() || field < 0 || field >= HSDDP_F_COUNT || b0 < 0 || b0 + nb > h->s.batch) return HSDDP_EINVAL;
+    for (int b = 0; b < nb; b++) {
+        int count, elems; const Traj& T = h->s.pb[b0 + b].tr[phase];
+        const std::vector<double>* v = field_ptr(h->s.ph[phase], T, field, count, elems);
+        size_t sz = (size_t)count * elems;
+        if (field == HSDDP_F_PHI) dst[b] = T.Phi;
+        else if (v) std::memcpy(dst + b * sz, v->data(), sizeof(double) * sz);
+    }
+    return 0;
+}
+float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h->s.solve_ms; }
+int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
+
+// ---------------------------------------------------------------- model-level probes (tests only)
+// continuous-time WB contact dynamics: qdd(18), grf(12)   (WBM.cpp:38-57 / testKKTDynamics.cpp:97-121)
+void oracle_wb_forward(const double* x, const double* u, const int* contact, double psi_dyn, double alpha, double* qdd, double* grf) {
+    WbParams P; P.psi_dyn = psi_dyn; P.bg_alpha = alpha;
+    double tau[18] = {0}; for (int i = 0; i < 12; i++) tau[6 + i] = u[i];
+    WbKKT K; wb_forward(P, x, x + 18, tau, contact, K);
+    std::memcpy(qdd, K.qdd, sizeof(K.qdd)); std::memcpy(grf, K.grf, sizeof(K.grf));
+}
+void oracle_wb_dynamics(const double* x, const double* u, const int* contact, double psi_dyn, double psi_kin, double alpha, double dt, double* xnext, double* y) {
+    WbParams P; P.psi_dyn = psi_dyn; P.psi_kin = psi_kin; P.bg_alpha = alpha; wb_dynamics(P, x, u, contact, dt, xnext, y);
+}
+void oracle_wb_dynamics_partial(const double* x, const double* u, const int* contact, double psi_dyn, double psi_kin, double alpha, double dt,
+                                double* A, double* B, double* C, double* D) {
+    WbParams P; P.psi_dyn = psi_dyn; P.psi_kin = psi_kin; P.bg_alpha = alpha; wb_dynamics_partial(P, x, u, contact, dt, A, B, C, D);
+}
+void oracle_wb_impact(const double* x, const int* cur, const int* nxt, double psi_dyn, double psi_kin, int impulse_quirk, double* xnext, double* Px) {
+    WbParams P; P.psi_dyn = psi_dyn; P.psi_kin = psi_kin; P.impulse_quirk = impulse_quirk != 0;
+    if (xnext) wb_impact(P, x, cur, nxt, xnext);
+    if (Px) wb_impact_partial(P, x, cur, nxt, Px);
+}
+// foot kinematics: pos(4x3), vel(4x3), J(4x3x18 row-major), Jv(4x3x18)
+void oracle_wb_foot_kin(const double* x, double psi_dyn, double psi_kin, double* pos, double* vel, double* J, double* Jv) {
+    WbParams P; P.psi_dyn = psi_dyn; P.psi_kin = psi_kin; WbFootKin F; wb_foot_kin(P, x, F, true);
+    std::memcpy(pos, F.pos, sizeof(F.pos)); std::memcpy(vel, F.vel, sizeof(F.vel)); std::memcpy(J, F.J, sizeof(F.J)); std::memcpy(Jv, F.Jv, sizeof(F.Jv));
+}
+// the four CasADi-equivalent kinematic derivative families at (q, v, qdd, F): each 4 x (3x18) or 4 x (18x18), column-major per block
+void oracle_wb_kin_derivs(const double* q, const double* v, const double* qdd, const double* F12, double psi_kin,
+                          double* dvel_dq, double* dacc_dq, double* dacc_dv, double* dJTF_dq) {
+    WbParams P; P.psi_dyn = psi_kin; P.psi_kin = psi_kin;
+    static WbDeriv D; int mask[4] = {1, 1, 1, 1};
+    for (int l = 0; l < 4; l++) {   // per-foot force derivative: evaluate with only foot l loaded
+        int ml[4] = {0, 0, 0, 0}; ml[l] = 1;
+        wb_derivs(P, q, v, qdd, false, F12, ml, D);
+        for (int j = 0; j < 18; j++) for (int i = 0; i < 18; i++) dJTF_dq[l * 324 + i + 18 * j] = D.dJTF[i][j];
+    }
+    wb_derivs(P, q, v, qdd, false, F12, mask, D);
+    for (int l = 0; l < 4; l++) for (int j = 0; j < 18; j++) for (int r = 0; r < 3; r++) {
+        dvel_dq[l * 54 + r + 3 * j] = D.dvel[l][r][j];
+        dacc_dq[l * 54 + r + 3 * j] = D.dacc[l][r][j];
+        dacc_dv[l * 54 + r + 3 * j] = D.dacc[l][r][18 + j];
+    }
+}
+void oracle_srb_xdot(const double* x, const double* u, const double* pf, const int* c, double* xd, double* Ac, double* Bc) {
+    srb_xdot<double>(x, u, pf, c, xd);
+    if (Ac && Bc) srb_partials_ct(x, u, pf, c, Ac, Bc);
+}
+
+}  // extern "C"
