@@ -1,0 +1,75 @@
+// Common definitions for the HIP HS-DDP kernels (gfx950).
+//
+// SPMD-phase style: a kernel body is a sequence of PHASES; inside a phase every lane/thread runs the
+// same lambda on its own id and communicates with other lanes only through LDS, phases are separated
+// by a workgroup barrier.  On the GPU a phase is `body(threadIdx.x); __syncthreads();`.
+// With -DHS_HOST_EMU (tests/_emu only: a CPU lane-emulator used to debug kernel logic in a container
+// that has no GPU — never built into or loaded by the product) a phase is a plain loop over ids.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifdef HS_HOST_EMU
+#define HD inline
+#define HS_SHARED static thread_local
+#define HS_PHASE(NT, ...) { for (int tid = 0; tid < (NT); ++tid) { __VA_ARGS__ } }
+#else
+#include <hip/hip_runtime.h>
+#define HD __device__ __forceinline__
+#define HS_SHARED __shared__
+#define HS_PHASE(NT, ...) { { const int tid = threadIdx.x; if (tid < (NT)) { __VA_ARGS__ } } __syncthreads(); }
+#endif
+
+namespace hs {
+
+constexpr int WAVE = 64;
+constexpr double GRAV = 9.81;
+
+// forward-mode scalar: value + one tangent
+struct Dual {
+    double v, d;
+    HD Dual() : v(0), d(0) {}
+    HD Dual(double a) : v(a), d(0) {}
+    HD Dual(double a, double b) : v(a), d(b) {}
+};
+HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+HD Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.v * b.d + a.d * b.v); }
+HD Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.d); }
+HD Dual operator*(Dual a, double b) { return Dual(a.v * b, a.d * b); }
+HD Dual operator+(Dual a, double b) { return Dual(a.v + b, a.d); }
+HD Dual operator-(Dual a, double b) { return Dual(a.v - b, a.d); }
+HD void sincos_(double a, double& s, double& c) { s = sin(a); c = cos(a); }
+HD void sincos_(Dual a, Dual& s, Dual& c) { double sv = sin(a.v), cv = cos(a.v); s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d); }
+HD double val(double a) { return a; }
+HD double val(Dual a) { return a.v; }
+HD double tang(double) { return 0.0; }
+HD double tang(Dual a) { return a.d; }
+template <class S> HD S mk(double v, bool seed);
+template <> HD double mk<double>(double v, bool) { return v; }
+template <> HD Dual mk<Dual>(double v, bool seed) { return Dual(v, seed ? 1.0 : 0.0); }
+
+template <class S> struct V3 { S x, y, z; };
+template <class S> HD V3<S> operator+(V3<S> a, V3<S> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class S> HD V3<S> operator-(V3<S> a, V3<S> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class S> HD V3<S> scale(S s, V3<S> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class S> HD V3<S> scaled(double s, V3<S> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class S> HD V3<S> cross(V3<S> a, V3<S> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// cross with a constant (double) vector
+template <class S> HD V3<S> crossc(V3<S> a, double bx, double by, double bz) { return {a.y * bz - a.z * by, a.z * bx - a.x * bz, a.x * by - a.y * bx}; }
+template <class S> HD V3<S> ccross(double ax, double ay, double az, V3<S> b) { return {ay * b.z - az * b.y, az * b.x - ax * b.z, ax * b.y - ay * b.x}; }
+
+// axis rotations: rot<AX>(c,s,w) = R_AX(theta) w ; rotT = R^T w
+template <int AX, class S, class T> HD V3<S> rot(T c, T s, V3<S> w) {
+    if (AX == 0) return {w.x, c * w.y - s * w.z, s * w.y + c * w.z};
+    if (AX == 1) return {c * w.x + s * w.z, w.y, c * w.z - s * w.x};
+    return {c * w.x - s * w.y, s * w.x + c * w.y, w.z};
+}
+template <int AX, class S, class T> HD V3<S> rotT(T c, T s, V3<S> w) {
+    if (AX == 0) return {w.x, c * w.y + s * w.z, c * w.z - s * w.y};
+    if (AX == 1) return {c * w.x - s * w.z, w.y, s * w.x + c * w.z};
+    return {c * w.x + s * w.y, c * w.y - s * w.x, w.z};
+}
+
+}  // namespace hs

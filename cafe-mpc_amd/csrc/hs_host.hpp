@@ -1,0 +1,114 @@
+// Host-side construction of the per-phase device descriptors from the C-ABI phase descriptors.
+// Templated on a memory policy so that the SAME layout code is used by libhsddp_hip.so (HIP memory) and by the
+// test-only lane emulator tests/_emu (plain host memory, used to debug kernel logic where no GPU exists).
+#pragma once
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "hsddp.h"
+#include "hs_types.hpp"
+
+namespace hs {
+
+inline int constraint_group(const PhaseDev& P, int c) {
+    if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) return 0;
+    if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) return 1;
+    if (P.go_height >= 0 && c == P.go_height) return 2;
+    return 3;
+}
+
+// Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes)
+template <class Mem>
+int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t* next, bool is_last, size_t B, PhaseDev& P, int slot0) {
+    std::memset(&P, 0, sizeof(P));
+    P.model = d.model; P.n = 36; P.m = 12; P.p = 12; P.h = d.horizon; P.dt = d.dt; P.bg_alpha = d.BG_alpha;
+    for (int l = 0; l < 4; l++) {
+        P.contact[l] = d.contact[l]; P.next_contact[l] = d.next_contact[l];
+        if (d.contact[l] > 0) P.feet[P.nc++] = l;
+        P.td[l] = (d.contact[l] == 0 && d.next_contact[l] == 1) ? 1 : 0; P.n_td += P.td[l];
+    }
+    P.has_impact = P.n_td > 0; P.next_model = d.next_model; P.shooting = d.shooting; P.is_last = is_last ? 1 : 0;
+    P.next_n = next ? (next->model == HSDDP_MODEL_WB ? 36 : next->model == HSDDP_MODEL_SRB ? 12 : 24) : 36;
+    std::memcpy(P.q, d.q, sizeof(P.q)); std::memcpy(P.r, d.r, sizeof(P.r)); std::memcpy(P.qf, d.qf, sizeof(P.qf));
+    std::memcpy(P.w_foot_reg, d.w_foot_reg, 24); std::memcpy(P.w_swing_pos, d.w_swing_pos, 24); std::memcpy(P.w_swing_vel, d.w_swing_vel, 24);
+    P.w_td_vel = d.w_td_vel;
+    P.c_torque = d.c_torque; P.c_joint = d.c_joint; P.c_minheight = d.c_minheight; P.c_grf = d.c_grf; P.c_touchdown = d.c_touchdown;
+    P.torque_limit = d.torque_limit; std::memcpy(P.joint_lb, d.joint_lb, 24); std::memcpy(P.joint_ub, d.joint_ub, 24);
+    P.h_min = d.h_min; P.mu = d.mu; P.ground_height = d.ground_height;
+    const hsddp_reb_t* rb[4] = {&d.reb_torque, &d.reb_joint, &d.reb_minheight, &d.reb_grf};
+    for (int g = 0; g < 4; g++) { P.reb_init[g][0] = rb[g]->delta; P.reb_init[g][1] = rb[g]->delta_min; P.reb_init[g][2] = rb[g]->eps; }
+    P.al_init[0] = d.al_td.sigma; P.al_init[1] = d.al_td.lambda; P.al_init[2] = d.al_td.sigma_max;
+    int ng = 0; P.go_torque = P.go_joint = P.go_height = P.go_grf = -1;
+    if (d.c_torque) { P.go_torque = ng; ng += 24; }
+    if (d.c_joint) { P.go_joint = ng; ng += 24; }
+    if (d.c_minheight) { P.go_height = ng; ng += 1; }
+    if (d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
+    P.ng = ng; P.nt = d.c_touchdown ? P.n_td : 0; P.slot0 = slot0;
+    const size_t h1 = P.h + 1, hh = P.h;
+    bool ok = true;
+    auto up = [&](const double** dst, const double* src, size_t cnt) { void* p = mem.alloc(cnt * 8); if (!p) { ok = false; return; } if (src) mem.upload(p, src, cnt * 8); *dst = (const double*)p; };
+    up(&P.xr, d.xr, h1 * 36); up(&P.ur, d.ur, h1 * 12); up(&P.yr, d.yr, h1 * 12);
+    up(&P.foot_pos, d.foot_pos, h1 * 12); up(&P.foot_vel, d.foot_vel, h1 * 12); up(&P.body_pos, d.body_pos, h1 * 3);
+    { void* p = mem.alloc(h1 * 4 * sizeof(int)); if (!p) ok = false; else { if (d.ref_contact) mem.upload(p, d.ref_contact, h1 * 4 * sizeof(int)); P.ref_contact = (const int*)p; } }
+    auto al = [&](double** dst, size_t cnt) { void* p = mem.alloc(std::max<size_t>(cnt, 1) * 8); if (!p) ok = false; *dst = (double*)p; };
+    double** sx[] = {&P.X, &P.Xbar, &P.Xsim, &P.Defect, &P.Defect_bar, &P.dX, &P.G};
+    for (auto p : sx) al(p, B * h1 * 36);
+    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu, &P.Y, &P.lu, &P.ly};
+    for (auto p : su) al(p, B * hh * 12);
+    double** s432[] = {&P.K, &P.Qux, &P.B, &P.C};
+    for (auto p : s432) al(p, B * hh * 432);
+    double** s144[] = {&P.Quu, &P.D, &P.luu, &P.lyy};
+    for (auto p : s144) al(p, B * hh * 144);
+    al(&P.A, B * hh * 1296); al(&P.lxx, B * hh * 1296); al(&P.lx, B * hh * 36); al(&P.l, B * hh); al(&P.lbase, B * hh);
+    al(&P.Phi, B); al(&P.Phibase, B); al(&P.Phix, B * 36); al(&P.Phixx, B * 1296); al(&P.H0, B * 1296); al(&P.Px, B * (size_t)P.next_n * 36);
+    al(&P.g, B * hh * ng); al(&P.delta, B * hh * ng); al(&P.eps, B * hh * ng);
+    al(&P.th, B * P.nt); al(&P.sigma, B * P.nt); al(&P.lambda, B * P.nt);
+    if (!ok) return HSDDP_ENOMEM;
+    // initial ReB / AL parameters (initialize_params, ConstraintsBase.h:173-180, 362-366)
+    if (ng > 0) {
+        std::vector<double> dl(hh * ng), ep(hh * ng);
+        for (size_t k = 0; k < hh; k++) for (int c = 0; c < ng; c++) { int grp = constraint_group(P, c); dl[k * ng + c] = P.reb_init[grp][0]; ep[k * ng + c] = P.reb_init[grp][2]; }
+        for (size_t b = 0; b < B; b++) { mem.upload(P.delta + b * hh * ng, dl.data(), dl.size() * 8); mem.upload(P.eps + b * hh * ng, ep.data(), ep.size() * 8); }
+    }
+    if (P.nt > 0) { std::vector<double> sg(B * P.nt, P.al_init[0]), lm(B * P.nt, P.al_init[1]); mem.upload(P.sigma, sg.data(), sg.size() * 8); mem.upload(P.lambda, lm.data(), lm.size() * 8); }
+    return HSDDP_OK;
+}
+
+inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems) {
+    const int n = P.n, m = P.m, p = P.p, h = P.h;
+    switch (f) {
+        case HSDDP_F_X: count = h + 1; elems = n; return P.X;
+        case HSDDP_F_XBAR: count = h + 1; elems = n; return P.Xbar;
+        case HSDDP_F_XSIM: count = h + 1; elems = n; return P.Xsim;
+        case HSDDP_F_DEFECT: count = h + 1; elems = n; return P.Defect;
+        case HSDDP_F_DX: count = h + 1; elems = n; return P.dX;
+        case HSDDP_F_G: count = h + 1; elems = n; return P.G;
+        case HSDDP_F_U: count = h; elems = m; return P.U;
+        case HSDDP_F_UBAR: count = h; elems = m; return P.Ubar;
+        case HSDDP_F_DU: count = h; elems = m; return P.dU;
+        case HSDDP_F_QU: count = h; elems = m; return P.Qu;
+        case HSDDP_F_Y: count = h; elems = p; return P.Y;
+        case HSDDP_F_K: count = h; elems = m * n; return P.K;
+        case HSDDP_F_QUX: count = h; elems = m * n; return P.Qux;
+        case HSDDP_F_QUU: count = h; elems = m * m; return P.Quu;
+        case HSDDP_F_A: count = h; elems = n * n; return P.A;
+        case HSDDP_F_B: count = h; elems = n * m; return P.B;
+        case HSDDP_F_C: count = h; elems = p * n; return P.C;
+        case HSDDP_F_D: count = h; elems = p * m; return P.D;
+        case HSDDP_F_L: count = h; elems = 1; return P.l;
+        case HSDDP_F_LX: count = h; elems = n; return P.lx;
+        case HSDDP_F_LU: count = h; elems = m; return P.lu;
+        case HSDDP_F_LY: count = h; elems = p; return P.ly;
+        case HSDDP_F_LXX: count = h; elems = n * n; return P.lxx;
+        case HSDDP_F_LUX: count = h; elems = m * n; return nullptr;   // identically zero for every shipped cost: not stored
+        case HSDDP_F_LUU: count = h; elems = m * m; return P.luu;
+        case HSDDP_F_LYY: count = h; elems = p * p; return P.lyy;
+        case HSDDP_F_PHI: count = 1; elems = 1; return P.Phi;
+        case HSDDP_F_PHIX: count = 1; elems = n; return P.Phix;
+        case HSDDP_F_PHIXX: count = 1; elems = n * n; return P.Phixx;
+        case HSDDP_F_H0: count = 1; elems = n * n; return P.H0;
+        default: count = 0; elems = 0; return nullptr;
+    }
+}
+
+}  // namespace hs

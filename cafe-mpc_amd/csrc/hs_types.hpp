@@ -1,0 +1,60 @@
+// Device-visible descriptors and per-problem solver state (shared by all kernels and the host driver).
+#pragma once
+#include "hs_common.hpp"
+
+namespace hs {
+
+constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 72;
+
+// Per-phase device descriptor.  Trajectory arrays are [batch][count][elems] (problem-major, horizon-major,
+// element-contiguous, matrices column-major) so that one wave reads/writes a knot's record with unit stride.
+struct PhaseDev {
+    int model, n, m, p, h;
+    double dt, bg_alpha;
+    int contact[4], next_contact[4], td[4], feet[4];
+    int nc, n_td, has_impact, next_model, next_n, shooting, is_last;
+    double q[MAXN], r[MAXM], qf[MAXN], w_foot_reg[3], w_swing_pos[3], w_swing_vel[3], w_td_vel;
+    int c_torque, c_joint, c_minheight, c_grf, c_touchdown;
+    double torque_limit, joint_lb[3], joint_ub[3], h_min, mu, ground_height;
+    double reb_init[4][3];   // torque, joint, minheight, grf : delta, delta_min, eps
+    double al_init[3];       // sigma, lambda, sigma_max
+    int ng, go_torque, go_joint, go_height, go_grf;   // path-constraint count and group offsets (-1: absent)
+    int nt;                                           // terminal constraints (touchdown feet)
+    int slot0;                                        // first global slot of this phase (slots = h+1 per phase)
+    // reference arrays shared by the batch: (h+1) x width
+    const double *xr, *ur, *yr, *foot_pos, *foot_vel, *body_pos;
+    const int* ref_contact;
+    // trajectories
+    double *X, *Xbar, *Xsim, *Defect, *Defect_bar, *dX, *G;           // (h+1) x n
+    double *U, *Ubar, *dU, *Qu;                                        // h x m
+    double *Y;                                                         // h x p
+    double *K, *Qux, *Quu;                                             // h x (m*n), h x (m*m)
+    double *A, *B, *C, *D;                                             // h x ...
+    double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
+    double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
+    double *g, *delta, *eps;                                           // h x ng
+    double *th, *sigma, *lambda;                                       // nt
+};
+
+// control flags of the per-problem state machine (MultiPhaseDDP::solve as masks over the batch)
+struct ProbState {
+    double actual_cost, merit, feas, dV_1, dV_2, merit_rho;
+    double cost_prev, merit_prev, feas_prev, reg;
+    double max_tconstr, max_pconstr, max_tconstr_prev, max_pconstr_prev;
+    double info_tconstr, info_pconstr;   // last buffered values (eqn/ineq_feas_buffer.back())
+    double ls_eps;
+    int iter, ls_total, reg_total, status;
+    int outer_active, inner_active, ls_active, ls_success, rollout_ok, bs_ok;
+    int iter_in, iter_ou;
+};
+
+struct OptDev {
+    double alpha, gamma, update_penalty, update_relax, update_regularization, update_ReB;
+    int max_DDP_iter, max_AL_iter;
+    double cost_thresh, tconstr_thresh, pconstr_thresh, dynamics_feas_thresh, merit_scale, merit_offset;
+    int AL_active, ReB_active, MS;
+};
+
+struct ModelDev { double cpsi_dyn, spsi_dyn, cpsi_kin, spsi_kin; };
+
+}  // namespace hs

@@ -1,0 +1,548 @@
+// libhsddp_hip.so — MI355X (gfx950) implementation of include/hsddp.h.
+//
+// Host driver of the batched HS-DDP solve: MultiPhaseDDP<T>::solve (HSDDPSolver/source/MultiPhaseDDP.cpp:216-447)
+// restructured as a per-problem state machine evaluated with masks over the whole batch, so that thousands of
+// independent problems advance through rollout / LQ approximation / Riccati sweep / line search in lock-step
+// kernel launches with no host round-trip inside an iteration (one 8-byte readback per inner iteration).
+// Kernels: wb_knot.hpp (one wavefront per knot), sweep.hpp (one workgroup per problem).
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cmath>
+#include "hsddp.h"
+#include "hs_types.hpp"
+#include "hs_host.hpp"
+#include "wb_knot.hpp"
+#include "sweep.hpp"
+
+using namespace hs;
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return HSDDP_ENODEV; } } while (0)
+
+struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
+
+// ------------------------------------------------------------------------------------------------ kernels
+enum { MASK_NONE = 0, MASK_LS = 1, MASK_INNER = 2, MASK_OUTER = 3, MASK_LS_OK = 4 };
+__device__ inline bool masked_out(const ProbState& s, int mask) {
+    if (mask == MASK_LS) return !s.ls_active;
+    if (mask == MASK_INNER) return !s.inner_active;
+    if (mask == MASK_OUTER) return !s.outer_active;
+    if (mask == MASK_LS_OK) return !s.ls_success;
+    return false;
+}
+
+__global__ void __launch_bounds__(64) k_rollout(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
+                                               double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail) {
+    const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
+    if (masked_out(st[b], mask)) return;
+    __shared__ WbLds L;
+    const int pi = slot_phase[s], k = slot_k[s];
+    const PhaseDev& P = ph[pi];
+    SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
+    const size_t slot = (size_t)b * nslots + s;
+    if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
+    else wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
+}
+
+__global__ void __launch_bounds__(64) k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
+                                          const ProbState* st, int mask) {
+    const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
+    if (masked_out(st[b], mask)) return;
+    __shared__ WbLds L;
+    const int pi = slot_phase[s], k = slot_k[s];
+    const PhaseDev& P = ph[pi];
+    if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active);
+    else wb_lq_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+}
+
+// cost-only refresh from stored g / h with the CURRENT ReB / AL parameters (SinglePhase::compute_cost, SinglePhase.cpp:236-262)
+__global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph, const int* slot_phase, const int* slot_k, int nslots, OptDev opt, SlotArrays sa,
+                                            const ProbState* st, int mask) {
+    const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
+    if (masked_out(st[b], mask)) return;
+    __shared__ double bar[MAXG];
+    const PhaseDev& P = ph[slot_phase[s]]; const int k = slot_k[s]; const int tid = threadIdx.x;
+    const size_t slot = (size_t)b * nslots + s;
+    if (k < P.h) {
+        const size_t kk = (size_t)b * P.h + k;
+        for (int c = tid; c < P.ng; c += 64) { size_t gi = kk * P.ng + c; bar[c] = P.eps[gi] * reb_barrier(P.g[gi], P.delta[gi]); }
+        __syncthreads();
+        if (tid == 0) {
+            double l = P.lbase[kk];
+            if (opt.ReB_active) {
+                int offs[4] = {P.go_torque, P.go_joint, P.go_height, P.go_grf}; int sz[4] = {24, 24, 1, 5 * P.nc};
+                for (int gI = 0; gI < 4; gI++) if (offs[gI] >= 0) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += bar[offs[gI] + i]; l += P.dt * c; }
+            }
+            P.l[kk] = l; sa.cost[slot] = l;
+        }
+    } else if (tid == 0) {
+        double Phi = P.Phibase[b], c = 0;
+        for (int i = 0; i < P.nt; i++) { double hh = P.th[(size_t)b * P.nt + i]; c += 0.5 * P.sigma[(size_t)b * P.nt + i] * hh * hh; c += P.lambda[(size_t)b * P.nt + i] * hh; }
+        if (opt.AL_active && P.nt > 0) Phi += c;
+        P.Phi[b] = Phi; sa.cost[slot] = Phi;
+    }
+}
+
+__global__ void __launch_bounds__(SW_NT) k_sweep(const PhaseDev* ph, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
+                                                int do_linear, double lin_eps, int* success_out) {
+    const int b = blockIdx.x;
+    if (masked_out(st[b], mask)) return;
+    __shared__ SweepLds S;
+    bool success = false;
+    if (regularized) {   // MultiPhaseDDP::backward_sweep_regularized (MultiPhaseDDP.cpp:136-165)
+        double reg = st[b].reg; int iter = 0;
+        while (true) {
+            iter++;
+            success = riccati_sweep<SW_NT>(S, ph, nph, b, reg);
+            if (success) break;
+            reg = fmax(reg * opt.update_regularization, 1e-3);
+            if (reg > 1e2) break;
+        }
+        reg = reg / 20; if (reg < 1e-6) reg = 0;
+        if (threadIdx.x == 0) { st[b].reg = reg; st[b].reg_total += iter; st[b].bs_ok = success ? 1 : 0; }
+    } else {
+        success = riccati_sweep<SW_NT>(S, ph, nph, b, fixed_reg);
+        if (threadIdx.x == 0 && success_out) success_out[b] = success ? 1 : 0;
+    }
+    if (success && do_linear) linear_rollout<SW_NT>(S, ph, nph, b, lin_eps);
+    __syncthreads();
+    if (threadIdx.x == 0) { st[b].dV_1 = S.dV1; st[b].dV_2 = S.dV2; }
+}
+
+__global__ void __launch_bounds__(SW_NT) k_linear(const PhaseDev* ph, int nph, ProbState* st, double eps) {
+    __shared__ SweepLds S;
+    linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
+    __syncthreads();
+    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.dV1; st[blockIdx.x].dV_2 = S.dV2; }
+}
+
+// X -> Xbar, U -> Ubar, Defect -> Defect_bar (Trajectory::update_nominal_vals, TrajectoryManagement.cpp:122-127)
+__global__ void k_update_nominal(const PhaseDev* ph, int nph, const ProbState* st, int mask) {
+    const int b = blockIdx.y;
+    if (masked_out(st[b], mask)) return;
+    for (int pi = 0; pi < nph; pi++) {
+        const PhaseDev& P = ph[pi];
+        const size_t nx = (size_t)(P.h + 1) * P.n, nu = (size_t)P.h * P.m;
+        for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (size_t)gridDim.x * blockDim.x) {
+            P.Xbar[b * nx + i] = P.X[b * nx + i]; P.Defect_bar[b * nx + i] = P.Defect[b * nx + i];
+        }
+        for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nu; i += (size_t)gridDim.x * blockDim.x) P.Ubar[b * nu + i] = P.U[b * nu + i];
+    }
+}
+
+// ReB / AL parameter updates (ConstraintsBase.h:194-209, 375-391) for problems flagged by k_outer_end (ls_success reused as flag? no: own mask)
+__global__ void k_update_params(const PhaseDev* ph, int nph, OptDev opt, const ProbState* st, const int* do_update) {
+    const int b = blockIdx.y;
+    if (!do_update[b]) return;
+    for (int pi = 0; pi < nph; pi++) {
+        const PhaseDev& P = ph[pi];
+        if (opt.ReB_active) {
+            const size_t tot = (size_t)P.h * P.ng;
+            for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+                const size_t gi = (size_t)b * tot + i; const int c = (int)(i % P.ng);
+                if (P.g[gi] > -opt.pconstr_thresh) continue;
+                int grp = (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) ? 0 : (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) ? 1 : (P.go_height >= 0 && c == P.go_height) ? 2 : 3;
+                P.eps[gi] *= opt.update_ReB;
+                P.delta[gi] = fmax(P.delta[gi] * opt.update_relax, P.reb_init[grp][1]);
+            }
+        }
+        if (opt.AL_active && blockIdx.x == 0 && (int)threadIdx.x < P.nt) {
+            const size_t ti = (size_t)b * P.nt + threadIdx.x; const double hh = P.th[ti];
+            if (!(fabs(hh) < opt.tconstr_thresh)) {
+                if (fabs(hh) > 0.005) { P.sigma[ti] = fmin(P.sigma[ti] * opt.update_penalty, P.al_init[2]); }
+                else P.lambda[ti] += hh * P.sigma[ti];
+            }
+        }
+    }
+}
+
+// Per-problem control: reduction of the per-slot partials + the scalar logic of MultiPhaseDDP::solve / line_search.
+enum { EV_REDUCE_ONLY = 0, EV_INIT, EV_OUTER_BEGIN, EV_INNER_BEGIN, EV_PRE_LS, EV_LS_TRIAL, EV_POST_LS, EV_OUTER_END, EV_TIMEOUT };
+__global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa, ProbState* st, OptDev opt, double eps, const int* fail, int* do_update,
+                                            int* counters, int iter_ou_host) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    ProbState& s = st[b];
+    __shared__ double rc[64], rd[64], rg[64], rh[64];
+    bool need_reduce = (mode == EV_REDUCE_ONLY) || (mode == EV_INIT) || (mode == EV_INNER_BEGIN && s.inner_active) || (mode == EV_LS_TRIAL && s.ls_active);
+    double cost = 0, dsq = 0, ming = 0, maxh = 0;
+    if (need_reduce) {
+        double c = 0, d = 0, g = 0, h = 0;
+        for (int i = tid; i < nslots; i += 64) { size_t j = (size_t)b * nslots + i; c += sa.cost[j]; d += sa.dsq[j]; g = fmin(g, sa.ming[j]); h = fmax(h, sa.maxh[j]); }
+        rc[tid] = c; rd[tid] = d; rg[tid] = g; rh[tid] = h;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) { if (tid < o) { rc[tid] += rc[tid + o]; rd[tid] += rd[tid + o]; rg[tid] = fmin(rg[tid], rg[tid + o]); rh[tid] = fmax(rh[tid], rh[tid + o]); } __syncthreads(); }
+        cost = rc[0]; dsq = rd[0]; ming = rg[0]; maxh = rh[0];
+    }
+    if (tid != 0) return;
+    switch (mode) {
+    case EV_REDUCE_ONLY: s.actual_cost = cost; s.feas = sqrt(dsq); s.max_pconstr = ming; s.max_tconstr = maxh; break;
+    case EV_INIT:   // MultiPhaseDDP.cpp:218-263
+        s.actual_cost = cost; s.feas = sqrt(dsq); s.max_pconstr = ming; s.max_tconstr = maxh;
+        s.info_tconstr = maxh; s.info_pconstr = ming; s.iter = 0; s.ls_total = 0; s.status = 0; s.reg = 0;
+        s.outer_active = 1; s.inner_active = 0; s.ls_active = 0; s.ls_success = 0; s.iter_in = 0; s.iter_ou = 0;
+        break;
+    case EV_OUTER_BEGIN:   // :267-276
+        if (s.outer_active) { s.iter_ou++; s.max_tconstr_prev = s.max_tconstr; s.max_pconstr_prev = s.max_pconstr; s.reg = 0; s.iter_in = 0; s.inner_active = 1; }
+        break;
+    case EV_INNER_BEGIN:   // :280-285  (compute_cost; feas)
+        if (s.inner_active) { s.actual_cost = cost; s.feas = sqrt(dsq); s.iter_in++; s.iter++; s.ls_success = 0; }
+        break;
+    case EV_PRE_LS:        // :315-349
+        s.ls_success = 0;
+        if (s.inner_active) {
+            if (!s.bs_ok) { s.status = 1; s.inner_active = 0; s.outer_active = 0; break; }   // bad_solve
+            double dV_abs = fabs(s.dV_1 + 0.5 * s.dV_2);
+            s.merit_rho = (s.feas > opt.dynamics_feas_thresh) ? dV_abs / ((1 - opt.merit_scale) * s.feas) + opt.merit_offset : 0;
+            s.merit = s.actual_cost + s.merit_rho * s.feas;
+            s.cost_prev = s.actual_cost; s.merit_prev = s.merit; s.feas_prev = s.feas;
+            if ((dV_abs < opt.cost_thresh) && (s.feas <= opt.dynamics_feas_thresh)) { s.inner_active = 0; s.ls_active = 0; }
+            else { s.ls_active = 1; s.ls_success = 0; }
+        }
+        break;
+    case EV_LS_TRIAL:      // MultiPhaseDDP::line_search body (:108-131)
+        if (s.ls_active) {
+            s.ls_total++;
+            bool rollout_success = fail[b] == 0;
+            s.actual_cost = cost; s.max_pconstr = ming; s.max_tconstr = maxh;
+            s.feas = sqrt(dsq);
+            s.merit = s.actual_cost + s.merit_rho * s.feas;
+            double exp_cost_change = eps * s.dV_1 + 0.5 * eps * eps * s.dV_2;
+            double exp_merit_change = exp_cost_change - eps * s.merit_rho * s.feas_prev;
+            if ((s.merit <= s.merit_prev + opt.gamma * exp_merit_change) && rollout_success) { s.ls_success = 1; s.ls_active = 0; s.ls_eps = eps; }
+        }
+        break;
+    case EV_POST_LS:       // :356-385
+        if (s.inner_active) {
+            s.ls_active = 0;
+            if (!s.ls_success) { s.actual_cost = s.cost_prev; s.merit = s.merit_prev; }
+            if ((fabs((s.cost_prev - s.actual_cost) / s.cost_prev) < opt.cost_thresh) && (s.feas <= opt.dynamics_feas_thresh)) s.inner_active = 0;
+            else { s.info_tconstr = s.max_tconstr; s.info_pconstr = s.max_pconstr; if (s.iter_in >= opt.max_DDP_iter) s.inner_active = 0; }
+        }
+        break;
+    case EV_OUTER_END:     // :394-426
+        do_update[b] = 0;
+        if (s.outer_active) {
+            s.inner_active = 0;
+            if (s.max_tconstr < opt.tconstr_thresh && fabs(s.max_pconstr) < opt.pconstr_thresh && s.feas <= opt.dynamics_feas_thresh) s.outer_active = 0;
+            else if (fabs(s.max_tconstr - s.max_tconstr_prev) < 0.0001 && fabs(s.max_pconstr - s.max_pconstr_prev) < 0.0001 && s.feas <= opt.dynamics_feas_thresh) s.outer_active = 0;
+            else { do_update[b] = 1; if (iter_ou_host >= opt.max_AL_iter) s.outer_active = 0; }
+        }
+        break;
+    case EV_TIMEOUT:
+        if (s.outer_active || s.inner_active) { s.status = 2; s.outer_active = 0; s.inner_active = 0; s.ls_active = 0; }
+        break;
+    }
+    if (counters) { if (s.inner_active) atomicAdd(&counters[0], 1); if (s.outer_active) atomicAdd(&counters[1], 1); if (s.ls_active) atomicAdd(&counters[2], 1); }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct DevBuf { void* p = nullptr; size_t bytes = 0; };
+
+struct hsddp_handle {
+    int nph = 0, batch = 0, device = 0, nslots = 0;
+    std::vector<PhaseDev> ph;         // host copy (device pointers inside)
+    PhaseDev* d_ph = nullptr;
+    int *d_slot_phase = nullptr, *d_slot_k = nullptr, *d_fail = nullptr, *d_do_update = nullptr, *d_counters = nullptr, *d_success = nullptr;
+    int* h_counters = nullptr;        // pinned
+    ProbState* d_st = nullptr;
+    double* d_x0 = nullptr;
+    SlotArrays sa{};
+    ModelDev md{};
+    std::vector<void*> allocs;
+    hipStream_t stream = nullptr;
+    float solve_ms = 0;
+    bool rolled = false;
+    // kernel timing
+    std::vector<std::string> kname; std::vector<double> kms; std::vector<long long> kcnt;
+    struct Ev { hipEvent_t a, b; int id; };
+    std::vector<Ev> pending;
+    std::vector<hipEvent_t> pool;
+    bool timing = true;
+};
+
+static int kid(hsddp_handle* h, const char* n) {
+    for (size_t i = 0; i < h->kname.size(); i++) if (h->kname[i] == n) return (int)i;
+    h->kname.push_back(n); h->kms.push_back(0); h->kcnt.push_back(0); return (int)h->kname.size() - 1;
+}
+static hipEvent_t get_event(hsddp_handle* h) { if (!h->pool.empty()) { hipEvent_t e = h->pool.back(); h->pool.pop_back(); return e; } hipEvent_t e; hipEventCreate(&e); return e; }
+struct Timed {
+    hsddp_handle* h; int id; hipEvent_t a, b;
+    Timed(hsddp_handle* h_, const char* n) : h(h_) { if (h->timing) { id = kid(h, n); a = get_event(h); b = get_event(h); hipEventRecord(a, h->stream); } }
+    ~Timed() { if (h->timing) { hipEventRecord(b, h->stream); h->pending.push_back({a, b, id}); } }
+};
+static void drain_events(hsddp_handle* h) {
+    for (auto& e : h->pending) { float ms = 0; hipEventSynchronize(e.b); hipEventElapsedTime(&ms, e.a, e.b); h->kms[e.id] += ms; h->kcnt[e.id]++; h->pool.push_back(e.a); h->pool.push_back(e.b); }
+    h->pending.clear();
+}
+
+template <class T> static int dalloc(hsddp_handle* h, T** out, size_t count, bool zero = true) {
+    void* p = nullptr; size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed: %s\n", bytes, hipGetErrorString(e)); return HSDDP_ENOMEM; }
+    if (zero) hipMemset(p, 0, bytes);
+    h->allocs.push_back(p); *out = (T*)p; return HSDDP_OK;
+}
+template <class T> static int dupload(hsddp_handle* h, const T** out, const T* src, size_t count) {
+    T* p = nullptr; int rc = dalloc(h, &p, count, src == nullptr); if (rc) return rc;
+    if (src) hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    *out = p; return HSDDP_OK;
+}
+
+static OptDev to_dev(const hsddp_option_t& o) {
+    OptDev d; d.alpha = o.alpha; d.gamma = o.gamma; d.update_penalty = o.update_penalty; d.update_relax = o.update_relax;
+    d.update_regularization = o.update_regularization; d.update_ReB = o.update_ReB; d.max_DDP_iter = o.max_DDP_iter; d.max_AL_iter = o.max_AL_iter;
+    d.cost_thresh = o.cost_thresh; d.tconstr_thresh = o.tconstr_thresh; d.pconstr_thresh = o.pconstr_thresh; d.dynamics_feas_thresh = o.dynamics_feas_thresh;
+    d.merit_scale = o.merit_scale; d.merit_offset = o.merit_offset; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d;
+}
+
+extern "C" {
+
+const char* hsddp_backend_name(void) { return "hip-gfx950"; }
+
+void hsddp_destroy(hsddp_handle_t* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    drain_events(h);
+    for (void* p : h->allocs) hipFree(p);
+    for (auto e : h->pool) hipEventDestroy(e);
+    if (h->h_counters) hipHostFree(h->h_counters);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
+    if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
+    for (int i = 0; i < n_phases; i++) {
+        if (phases[i].model != HSDDP_MODEL_WB) { fprintf(stderr, "[hsddp_hip] phase %d: only the whole-body model runs on the HIP backend in this build\n", i); return HSDDP_ENOTSUP; }
+        if (!phases[i].shooting) { fprintf(stderr, "[hsddp_hip] single-shooting phases are not supported (knot-parallel multiple shooting only)\n"); return HSDDP_ENOTSUP; }
+        if (phases[i].horizon <= 0) return HSDDP_EINVAL;
+    }
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { fprintf(stderr, "[hsddp_hip] no HIP device %d\n", device); return HSDDP_ENODEV; }
+    HIPCK(hipSetDevice(device));
+    hsddp_handle* h = new hsddp_handle();
+    h->nph = n_phases; h->batch = batch; h->device = device;
+    HIPCK(hipStreamCreate(&h->stream));
+    double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI;
+    h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
+    h->ph.resize(n_phases);
+    std::vector<int> sp, sk;
+    const size_t B = batch;
+    int rc = 0;
+    struct HipMem {
+        hsddp_handle* h;
+        void* alloc(size_t bytes) { void* p = nullptr; bytes = std::max<size_t>(bytes, 8); if (hipMalloc(&p, bytes) != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed\n", bytes); return nullptr; } hipMemset(p, 0, bytes); h->allocs.push_back(p); return p; }
+        void upload(void* dst, const void* src, size_t bytes) { hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+    } mem{h};
+    for (int i = 0; i < n_phases && !rc; i++) {
+        rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, h->ph[i], (int)sp.size());
+        for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
+    }
+    h->nslots = (int)sp.size();
+    if (!rc) rc |= dalloc(h, &h->d_ph, n_phases);
+    if (!rc) rc |= dalloc(h, &h->d_slot_phase, sp.size()); if (!rc) rc |= dalloc(h, &h->d_slot_k, sk.size());
+    if (!rc) rc |= dalloc(h, &h->d_fail, B); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
+    if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * 36);
+    if (!rc) rc |= dalloc(h, &h->sa.cost, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * sp.size());
+    if (!rc) rc |= dalloc(h, &h->sa.ming, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * sp.size());
+    if (rc) { hsddp_destroy(h); return rc; }
+    hipMemcpy(h->d_ph, h->ph.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice);
+    hipMemcpy(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice);
+    hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int));
+    HIPCK(hipDeviceSynchronize());
+    *out = h; return HSDDP_OK;
+}
+
+int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) {
+    if (!h || !x0) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    HIPCK(hipMemcpy(h->d_x0, x0, (size_t)h->batch * 36 * 8, hipMemcpyHostToDevice));
+    return HSDDP_OK;
+}
+
+int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per_problem) {
+    if (!h || phase < 0 || phase >= h->nph) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    PhaseDev& P = h->ph[phase]; const size_t sx = (size_t)(P.h + 1) * 36, su = (size_t)P.h * 12, B = h->batch;
+    for (size_t b = 0; b < B; b++) {
+        if (Xbar) { const double* s = Xbar + (per_problem ? b * sx : 0); hipMemcpy(P.Xbar + b * sx, s, sx * 8, hipMemcpyHostToDevice); hipMemcpy(P.X + b * sx, s, sx * 8, hipMemcpyHostToDevice); }
+        if (Ubar) { const double* s = Ubar + (per_problem ? b * su : 0); hipMemcpy(P.Ubar + b * su, s, su * 8, hipMemcpyHostToDevice); hipMemcpy(P.U + b * su, s, su * 8, hipMemcpyHostToDevice); }
+    }
+    HIPCK(hipMemset(P.K, 0, B * P.h * 432 * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
+    return HSDDP_OK;
+}
+
+// ---- launch helpers
+static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask) {
+    Timed t(h, "k_rollout");
+    hipMemsetAsync(h->d_fail, 0, h->batch * sizeof(int), h->stream);
+    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md,
+                       eps, o, h->d_x0, h->sa, h->d_st, mask, h->d_fail);
+}
+static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
+    Timed t(h, "k_lq");
+    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask);
+}
+static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
+    Timed t(h, "k_cost");
+    hipLaunchKernelGGL(k_cost, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->d_slot_phase, h->d_slot_k, h->nslots, o, h->sa, h->d_st, mask);
+}
+static void launch_sweep(hsddp_handle* h, const OptDev& o, int mask, double reg, int regularized, int do_linear, double lin_eps, int* succ) {
+    Timed t(h, "k_sweep");
+    hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ);
+}
+static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, bool count, int iter_ou) {
+    Timed t(h, "k_eval");
+    if (count) hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
+    hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou);
+    if (count) hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+}
+static void launch_update_nominal(hsddp_handle* h, int mask) {
+    Timed t(h, "k_update_nominal");
+    hipLaunchKernelGGL(k_update_nominal, dim3(8, h->batch), dim3(256), 0, h->stream, h->d_ph, h->nph, h->d_st, mask);
+}
+
+int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_ms) {
+    if (!h || !opt) return HSDDP_EINVAL;
+    if (!opt->MS) { fprintf(stderr, "[hsddp_hip] MS=false (single shooting) is not supported on the HIP backend\n"); return HSDDP_ENOTSUP; }
+    HIPCK(hipSetDevice(h->device));
+    const OptDev o = to_dev(*opt);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    auto elapsed = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(); };
+    const bool budget = max_cputime_ms < 1e5f;
+    auto timeup = [&]() { if (!budget) return false; hipStreamSynchronize(h->stream); float e = elapsed(); return e > max_cputime_ms || fabsf(e - max_cputime_ms) <= 1e-6f; };
+    bool timed_out = false;
+    // initial rollout (MultiPhaseDDP.cpp:238-241)
+    launch_rollout(h, 0.0, o, MASK_NONE);
+    launch_update_nominal(h, MASK_NONE);
+    launch_eval(h, EV_INIT, o, 0.0, false, 0);
+    for (int iter_ou = 1; iter_ou <= opt->max_AL_iter && !timed_out; iter_ou++) {
+        launch_eval(h, EV_OUTER_BEGIN, o, 0.0, false, iter_ou);
+        for (int iter_in = 1; iter_in <= opt->max_DDP_iter && !timed_out; iter_in++) {
+            if (iter_in == 1 && iter_ou > 1) launch_cost(h, o, MASK_INNER);   // parameters changed: refresh costs
+            launch_eval(h, EV_INNER_BEGIN, o, 0.0, false, iter_ou);
+            if (timeup()) { timed_out = true; break; }
+            launch_lq(h, o, MASK_INNER);
+            if (timeup()) { timed_out = true; break; }
+            launch_sweep(h, o, MASK_INNER, 0.0, 1, 1, 1.0, nullptr);
+            if (timeup()) { timed_out = true; break; }
+            launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
+            double eps = 1.0;
+            while (eps > 1e-3) {
+                launch_rollout(h, eps, o, MASK_LS);
+                launch_eval(h, EV_LS_TRIAL, o, eps, true, iter_ou);
+                eps *= opt->alpha;
+                // stop issuing trials once no problem is still searching (cheap 16-byte readback)
+                hipStreamSynchronize(h->stream);
+                if (h->h_counters[2] == 0) break;
+            }
+            launch_update_nominal(h, MASK_LS_OK);
+            launch_eval(h, EV_POST_LS, o, 0.0, true, iter_ou);
+            if (timeup()) { timed_out = true; break; }
+            hipStreamSynchronize(h->stream);
+            if (h->h_counters[0] == 0) break;
+        }
+        if (timed_out) break;
+        launch_eval(h, EV_OUTER_END, o, 0.0, true, iter_ou);
+        {
+            Timed t(h, "k_update_params");
+            hipLaunchKernelGGL(k_update_params, dim3(8, h->batch), dim3(256), 0, h->stream, h->d_ph, h->nph, o, h->d_st, h->d_do_update);
+        }
+        hipStreamSynchronize(h->stream);
+        if (h->h_counters[1] == 0) break;
+    }
+    if (timed_out) launch_eval(h, EV_TIMEOUT, o, 0.0, false, 0);
+    HIPCK(hipStreamSynchronize(h->stream));
+    h->solve_ms = elapsed();
+    drain_events(h);
+    HIPCK(hipGetLastError());
+    return HSDDP_OK;
+}
+
+// ---- step API (MultiPhaseDDP public methods)
+int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
+    if (!h || !opt) return HSDDP_EINVAL; if (!opt->MS) return HSDDP_ENOTSUP;
+    HIPCK(hipSetDevice(h->device)); OptDev o = to_dev(*opt);
+    launch_rollout(h, eps, o, MASK_NONE); launch_eval(h, EV_REDUCE_ONLY, o, 0.0, false, 0);
+    HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
+}
+int hsddp_compute_cost(hsddp_handle_t* h, const hsddp_option_t* opt) {
+    if (!h || !opt) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device)); OptDev o = to_dev(*opt);
+    launch_cost(h, o, MASK_NONE); launch_eval(h, EV_REDUCE_ONLY, o, 0.0, false, 0);
+    HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
+}
+int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
+    if (!h || !opt) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device)); OptDev o = to_dev(*opt);
+    launch_lq(h, o, MASK_NONE); HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
+}
+int hsddp_backward_sweep(hsddp_handle_t* h, double regularization, int* success) {
+    if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device)); OptDev o{};
+    launch_sweep(h, o, MASK_NONE, regularization, 0, 0, 0.0, h->d_success);
+    HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError());
+    if (success) HIPCK(hipMemcpy(success, h->d_success, h->batch * sizeof(int), hipMemcpyDeviceToHost));
+    return HSDDP_OK;
+}
+int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
+    (void)opt; if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device));
+    { Timed t(h, "k_linear"); hipLaunchKernelGGL(k_linear, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps); }
+    HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
+}
+int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {
+    if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device));
+    launch_update_nominal(h, MASK_NONE); HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); return HSDDP_OK;
+}
+static int read_states(hsddp_handle* h, std::vector<ProbState>& st) {
+    st.resize(h->batch); HIPCK(hipSetDevice(h->device));
+    HIPCK(hipMemcpy(st.data(), h->d_st, sizeof(ProbState) * h->batch, hipMemcpyDeviceToHost)); return HSDDP_OK;
+}
+int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* dV_1, double* dV_2) {
+    std::vector<ProbState> st; int rc = read_states(h, st); if (rc) return rc;
+    for (int b = 0; b < h->batch; b++) { dV_1[b] = st[b].dV_1; dV_2[b] = st[b].dV_2; } return HSDDP_OK;
+}
+int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* feas) {
+    std::vector<ProbState> st; int rc = read_states(h, st); if (rc) return rc;
+    for (int b = 0; b < h->batch; b++) feas[b] = st[b].feas; return HSDDP_OK;
+}
+int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) {
+    if (!h || !info) return HSDDP_EINVAL;
+    std::vector<ProbState> st; int rc = read_states(h, st); if (rc) return rc;
+    for (int b = 0; b < h->batch; b++) {
+        info[b].actual_cost = st[b].actual_cost; info[b].dyn_feas = st[b].feas; info[b].max_tconstr = st[b].info_tconstr; info[b].max_pconstr = st[b].info_pconstr;
+        info[b].n_iters = st[b].iter; info[b].n_ls_iters = st[b].ls_total; info[b].n_reg_iters = st[b].reg_total; info[b].status = st[b].status;
+    }
+    return HSDDP_OK;
+}
+
+int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) {
+    if (!h || phase < 0 || phase >= h->nph || field < 0 || field >= HSDDP_F_COUNT) return HSDDP_EINVAL;
+    field_dev(h->ph[phase], field, *count, *elems); return HSDDP_OK;
+}
+int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
+    if (!h || phase < 0 || phase >= h->nph || field < 0 || field >= HSDDP_F_COUNT || b0 < 0 || nb < 0 || b0 + nb > h->batch || !dst) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    int count, elems; const double* src = field_dev(h->ph[phase], field, count, elems);
+    const size_t sz = (size_t)count * elems;
+    if (!src) { memset(dst, 0, sz * nb * 8); return HSDDP_OK; }
+    HIPCK(hipMemcpy(dst, src + (size_t)b0 * sz, sz * nb * 8, hipMemcpyDeviceToHost));
+    return HSDDP_OK;
+}
+float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h ? h->solve_ms : 0.f; }
+
+int hsddp_get_kernel_times(hsddp_handle_t* h, int max_n, double* ms, long long* launches, char* names, int names_cap) {
+    if (!h) return 0;
+    int n = std::min<int>(max_n, (int)h->kname.size()); int pos = 0;
+    for (int i = 0; i < n; i++) {
+        ms[i] = h->kms[i]; launches[i] = h->kcnt[i];
+        int len = (int)h->kname[i].size();
+        if (pos + len + 1 < names_cap) { memcpy(names + pos, h->kname[i].c_str(), len + 1); pos += len + 1; }
+    }
+    if (pos < names_cap) names[pos] = 0;
+    return n;
+}
+int hsddp_reset_kernel_times(hsddp_handle_t* h) { if (!h) return HSDDP_EINVAL; for (auto& v : h->kms) v = 0; for (auto& v : h->kcnt) v = 0; return HSDDP_OK; }
+
+}  // extern "C"

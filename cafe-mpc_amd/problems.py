@@ -122,7 +122,7 @@ def wb_phase(horizon, dt, t_offset, contact, next_contact, refs, next_model=MODE
     bufs["ref_contact"] = rc
     d.ref_contact = rc.ctypes.data_as(IP)
     ubar = np.zeros((horizon, m))
-    if ubar_mode == "gravity_comp":
+    if ubar_mode == "gravity_comp":  # "zero" reproduces testMHPCProblem.cpp:70-76
         ubar[:] = wb_gravity_comp_torque(bufs["xr"][0, :18], contact)
     return {"desc": d, "bufs": bufs, "Xbar": bufs["xr"].copy(), "Ubar": ubar}
 

@@ -1,0 +1,115 @@
+// TEST-ONLY lane emulator (never part of the product; not loadable through the package).
+// Compiles the HIP kernel programs of cafe-mpc_amd/csrc (wb_knot.hpp, sweep.hpp) for the HOST with
+// -DHS_HOST_EMU, where a "phase" becomes a loop over lane ids, so that kernel LOGIC (indexing, phase ordering,
+// per-lane math) can be checked against the oracle in a container that has no GPU.  It says nothing about
+// the real HIP execution (barriers, LDS, occupancy): the -m gpu tests do that through libhsddp_hip.so.
+#define HS_HOST_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "hsddp.h"
+#include "hs_types.hpp"
+#include "hs_host.hpp"
+#include "wb_knot.hpp"
+#include "sweep.hpp"
+
+using namespace hs;
+
+struct hsddp_handle {
+    int nph = 0, batch = 0, nslots = 0;
+    std::vector<PhaseDev> ph;
+    std::vector<int> sp, sk;
+    std::vector<double> x0, cost, dsq, ming, maxh, dV1, dV2, feas, acost;
+    std::vector<int> fail;
+    ModelDev md;
+    std::vector<void*> allocs;
+};
+struct HostMem {
+    hsddp_handle* h;
+    void* alloc(size_t bytes) { void* p = calloc(bytes < 8 ? 8 : bytes, 1); h->allocs.push_back(p); return p; }
+    void upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+};
+
+extern "C" {
+const char* hsddp_backend_name(void) { return "host-lane-emulator"; }
+int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int) {
+    hsddp_handle* h = new hsddp_handle(); h->nph = n_phases; h->batch = batch;
+    double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI; h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
+    h->ph.resize(n_phases); HostMem mem{h};
+    for (int i = 0; i < n_phases; i++) {
+        if (phases[i].model != HSDDP_MODEL_WB) return HSDDP_ENOTSUP;
+        int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, batch, h->ph[i], (int)h->sp.size());
+        if (rc) return rc;
+        for (int k = 0; k <= phases[i].horizon; k++) { h->sp.push_back(i); h->sk.push_back(k); }
+    }
+    h->nslots = h->sp.size(); size_t t = (size_t)batch * h->nslots;
+    h->cost.assign(t, 0); h->dsq.assign(t, 0); h->ming.assign(t, 0); h->maxh.assign(t, 0); h->x0.assign((size_t)batch * 36, 0);
+    h->dV1.assign(batch, 0); h->dV2.assign(batch, 0); h->feas.assign(batch, 0); h->acost.assign(batch, 0); h->fail.assign(batch, 0);
+    *out = h; return 0;
+}
+void hsddp_destroy(hsddp_handle_t* h) { if (!h) return; for (void* p : h->allocs) free(p); delete h; }
+int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) { memcpy(h->x0.data(), x0, h->x0.size() * 8); return 0; }
+int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per) {
+    PhaseDev& P = h->ph[phase]; size_t sx = (size_t)(P.h + 1) * 36, su = (size_t)P.h * 12;
+    for (size_t b = 0; b < (size_t)h->batch; b++) {
+        if (Xbar) { memcpy(P.Xbar + b * sx, Xbar + (per ? b * sx : 0), sx * 8); memcpy(P.X + b * sx, Xbar + (per ? b * sx : 0), sx * 8); }
+        if (Ubar) { memcpy(P.Ubar + b * su, Ubar + (per ? b * su : 0), su * 8); memcpy(P.U + b * su, Ubar + (per ? b * su : 0), su * 8); }
+    }
+    memset(P.K, 0, (size_t)h->batch * P.h * 432 * 8); memset(P.dU, 0, h->batch * su * 8); memset(P.dX, 0, h->batch * sx * 8);
+    return 0;
+}
+static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
+int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
+    OptDev o = to_dev(*opt); SlotOut so{h->cost.data(), h->dsq.data(), h->ming.data(), h->maxh.data()};
+    static WbLds L;
+    for (int b = 0; b < h->batch; b++) {
+        h->fail[b] = 0;
+        for (int s = 0; s < h->nslots; s++) {
+            int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi]; size_t slot = (size_t)b * h->nslots + s;
+            if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+            else wb_rollout_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, eps, o.AL_active, so, slot);
+        }
+        double c = 0, d = 0; for (int s = 0; s < h->nslots; s++) { c += h->cost[(size_t)b * h->nslots + s]; d += h->dsq[(size_t)b * h->nslots + s]; }
+        h->acost[b] = c; h->feas[b] = sqrt(d);
+    }
+    return 0;
+}
+int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }
+int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
+    OptDev o = to_dev(*opt); static WbLds L;
+    for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
+        int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
+        if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
+        else wb_lq_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
+    }
+    return 0;
+}
+int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
+    static SweepLds S;
+    for (int b = 0; b < h->batch; b++) { bool ok = riccati_sweep<SW_NT>(S, h->ph.data(), h->nph, b, reg); if (success) success[b] = ok; h->dV1[b] = S.dV1; h->dV2[b] = S.dV2; }
+    return 0;
+}
+int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t*) {
+    static SweepLds S;
+    for (int b = 0; b < h->batch; b++) { linear_rollout<SW_NT>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.dV1; h->dV2[b] = S.dV2; }
+    return 0;
+}
+int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {
+    for (auto& P : h->ph) { size_t nx = (size_t)h->batch * (P.h + 1) * 36, nu = (size_t)h->batch * P.h * 12; memcpy(P.Xbar, P.X, nx * 8); memcpy(P.Defect_bar, P.Defect, nx * 8); memcpy(P.Ubar, P.U, nu * 8); }
+    return 0;
+}
+int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* a, double* b) { memcpy(a, h->dV1.data(), h->batch * 8); memcpy(b, h->dV2.data(), h->batch * 8); return 0; }
+int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* f) { memcpy(f, h->feas.data(), h->batch * 8); return 0; }
+int hsddp_solve(hsddp_handle_t*, const hsddp_option_t*, float) { return HSDDP_ENOTSUP; }
+int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) { for (int b = 0; b < h->batch; b++) { memset(&info[b], 0, sizeof(info[b])); info[b].actual_cost = h->acost[b]; info[b].dyn_feas = h->feas[b]; } return 0; }
+int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) { field_dev(h->ph[phase], field, *count, *elems); return 0; }
+int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
+    int count, elems; const double* src = field_dev(h->ph[phase], field, count, elems); size_t sz = (size_t)count * elems;
+    if (!src) { memset(dst, 0, sz * nb * 8); return 0; }
+    memcpy(dst, src + (size_t)b0 * sz, sz * nb * 8); return 0;
+}
+float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
+int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
+}

@@ -1,0 +1,98 @@
+"""GPU parity tests: libhsddp_hip.so (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (fp64): every trajectory field relative 1e-8 of its scale per iterate; feedback gains
+||K_gpu - K_cpu||_inf < 1e-6 absolute (BASELINE.json north_star); iteration / line-search / regularisation
+counts identical.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg, ROOT
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backend_is_hip(hip_lib):
+    assert hip_lib.hsddp_backend_name() == b"hip-gfx950"
+
+
+def test_kkt_golden_vectors_gpu(hip_lib):
+    """testKKTDynamics.cpp:97-121 golden vectors through the HIP rollout kernel (one-knot phase, psi = pi)."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "kkt_golden.json")))
+    dt = 0.01
+    for contact, key in (((1, 1, 1, 1), "full_contact"), ((0, 0, 0, 0), "free_fall")):
+        ph = pkg.problems.wb_stance_problem(horizon=1, dt=dt, contact=contact, ubar_mode="zero")
+        ph[0]["Xbar"][:] = 1.0
+        s = pkg.Solver(hip_lib, ph, batch=1, psi_dyn=np.pi, psi_kin=np.pi)
+        s.set_nominal(0, ph[0]["Xbar"], ph[0]["Ubar"]); s.set_initial_condition(np.ones((1, 36)))
+        s.hybrid_rollout(0.0, pkg.mhpc_ddp_setting())
+        xs = s.field(0, "XSIM")[0, 1]
+        qdd = (xs[18:] - 1.0) / dt
+        assert np.abs(qdd - g[key + "_qdd"]).max() < 2e-4      # 4-decimal fixture + 1/dt amplification of rounding
+        if key == "full_contact":
+            assert np.abs(s.field(0, "Y")[0, 0] - g["full_contact_grf"]).max() < 1e-4
+        assert np.abs(xs[:18] - (1.0 + dt)).max() < 1e-14
+
+
+@pytest.mark.parametrize("which", ["stance", "trot"])
+def test_per_iterate_parity(hip_lib, oracle_lib, which):
+    phases = pkg.problems.wb_stance_problem(horizon=12) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(7, 6, 5, 6))
+    x0 = pkg.problems.wb_ensemble_x0(3, 20241222)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    pc.run_steps(pkg, so, sg, phases, pkg.mhpc_ddp_setting(), n_iter=3)
+
+
+def test_full_solve_parity_trot(hip_lib, oracle_lib):
+    """BASELINE config 2 shape at reduced horizon: 4 contact phases, AL + ReB active, converge mode."""
+    phases = pkg.problems.wb_trot_problem(horizons=(12, 12, 12, 12))
+    x0 = pkg.problems.wb_ensemble_x0(4, 20241222)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=3, max_DDP_iter=4)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
+    assert (sg.info_arrays()["n_iters"] > 2).all()
+
+
+def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):
+    """Fixed-work mode of SURVEY 8(d): max_AL_iter=1, cost_thresh=0 -> every problem runs max_DDP_iter iterations."""
+    phases = pkg.problems.wb_trot_problem(horizons=(10, 10, 10, 10))
+    x0 = pkg.problems.wb_ensemble_x0(5, 20241223)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=4, cost_thresh=0.0)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    assert (sg.info_arrays()["n_iters"] == 4).all()
+    pc.compare_solve(so, sg, len(phases))
+
+
+def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib):
+    """Ubar = 0 (testMHPCProblem.cpp:70-76): hard start that exercises multi-trial line searches and rejected steps."""
+    phases = pkg.problems.wb_stance_problem(horizon=10, ubar_mode="zero")
+    x0 = pkg.problems.wb_ensemble_x0(3, 7)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    assert np.array_equal(ia["n_ls_iters"], ib["n_ls_iters"]) and (ia["n_ls_iters"] > ia["n_iters"]).any()
+    pc.compare_solve(so, sg, 1, rtol=1e-5, atol_K=1e-5)
+
+
+def test_batch_independence_and_full_size_properties(hip_lib):
+    """Size-independent properties at BASELINE config-3 knot count (N=200, 4 phases): problems are independent
+    (same x0 in different batch slots -> bit-identical results), defects close under a full step."""
+    phases = pkg.problems.wb_trot_problem()
+    x0 = pkg.problems.wb_ensemble_x0(3, 20241222)
+    x0 = np.vstack([x0, x0[:1]])            # slot 3 duplicates slot 0
+    s = pkg.MultiPhaseDDP(phases, batch=4)
+    s.set_initial_condition(x0)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=3, cost_thresh=0.0)
+    s.solve(opt)
+    for f in ("XBAR", "UBAR", "K"):
+        a = s.field(0, f)
+        assert np.array_equal(a[0], a[3])
+    info = s.info_arrays()
+    assert (info["status"] == 0).all() and (info["n_iters"] == 3).all()
+    assert (info["dyn_feas"] < 0.5).all()       # started at ~6: multiple-shooting defects are being closed

@@ -1,0 +1,26 @@
+"""CPU test: the HIP kernel programs (cafe-mpc_amd/csrc/wb_knot.hpp, sweep.hpp) compiled for the host by the
+test-only lane emulator tests/_emu, checked against the oracle.  Catches indexing / phase-order / per-lane math
+errors without a GPU; real HIP execution is covered by the -m gpu tests."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from conftest import pkg, ROOT
+import parity_common as pc
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    d = os.path.join(ROOT, "tests", "_emu")
+    subprocess.check_call(["make", "-C", d, "-s"])
+    return pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu.so")))
+
+
+@pytest.mark.parametrize("which", ["stance", "trot"])
+def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
+    phases = pkg.problems.wb_stance_problem(horizon=5) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+    x0 = pkg.problems.wb_ensemble_x0(2, 20241222)
+    so, se = pc.make_pair(pkg, oracle_lib, emu_lib, phases, x0)
+    pc.run_steps(pkg, so, se, phases, pkg.mhpc_ddp_setting(), n_iter=2)
