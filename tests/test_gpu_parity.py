@@ -70,9 +70,9 @@ def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):
 
 def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib):
     """Ubar = 0 (testMHPCProblem.cpp:70-76): hard start that exercises multi-trial line searches and rejected steps."""
-    phases = pkg.problems.wb_stance_problem(horizon=10, ubar_mode="zero")
-    x0 = pkg.problems.wb_ensemble_x0(3, 7)
-    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2)
+    phases = pkg.problems.wb_stance_problem(horizon=50, ubar_mode="zero")     # BASELINE config 1 literal
+    x0 = np.vstack([pkg.problems.wb_nominal_state()[None], pkg.problems.wb_ensemble_x0(2, 7)])
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=1)
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
     so.solve(opt); sg.solve(opt)
     ia, ib = so.info_arrays(), sg.info_arrays()
