@@ -13,11 +13,16 @@
 #define HD inline
 #define HS_SHARED static thread_local
 #define HS_PHASE(NT, ...) { for (int tid = 0; tid < (NT); ++tid) { __VA_ARGS__ } }
+// wave-level phase: only the first 64 threads of the workgroup run it, ordered by a wave barrier (no s_barrier)
+#define HS_WPHASE(...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
 #define HS_SHARED __shared__
 #define HS_PHASE(NT, ...) { { const int tid = threadIdx.x; if (tid < (NT)) { __VA_ARGS__ } } __syncthreads(); }
+// wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program
+// order, so the only thing to prevent is compiler motion across the phase boundary.
+#define HS_WPHASE(...) { if (threadIdx.x < 64) { const int tid = threadIdx.x; { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
 namespace hs {
