@@ -23,6 +23,16 @@ using namespace hs;
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return HSDDP_ENODEV; } } while (0)
 
 struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
+#ifdef ROLL_WPE
+#define ROLL_ATTR __attribute__((amdgpu_waves_per_eu(ROLL_WPE, ROLL_WPE)))
+#else
+#define ROLL_ATTR
+#endif
+#ifdef LQ_WPE
+#define LQ_ATTR __attribute__((amdgpu_waves_per_eu(LQ_WPE, LQ_WPE)))
+#else
+#define LQ_ATTR
+#endif
 
 // ------------------------------------------------------------------------------------------------ kernels
 enum { MASK_NONE = 0, MASK_LS = 1, MASK_INNER = 2, MASK_OUTER = 3, MASK_LS_OK = 4 };
@@ -34,11 +44,11 @@ __device__ inline bool masked_out(const ProbState& s, int mask) {
     return false;
 }
 
-__global__ void __launch_bounds__(64) k_rollout(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
+__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
                                                double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail) {
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
-    __shared__ WbLds L;
+    __shared__ WbCore L;
     const int pi = slot_phase[s], k = slot_k[s];
     const PhaseDev& P = ph[pi];
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
@@ -47,11 +57,11 @@ __global__ void __launch_bounds__(64) k_rollout(const PhaseDev* ph, int nph, con
     else wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
 }
 
-__global__ void __launch_bounds__(64) k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
+__global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
                                           const ProbState* st, int mask) {
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
-    __shared__ WbLds L;
+    __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
     const PhaseDev& P = ph[pi];
     if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active);

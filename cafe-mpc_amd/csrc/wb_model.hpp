@@ -29,12 +29,9 @@ struct LaneCfg {
     int tq, tv;          // tangent seed index into q or v (-1: none)
 };
 
-// per-lane outputs of one pass
-template <class S> struct PassOut {
-    S tau[18];
-    V3<S> fpos[4], fvel[4], facc[4];   // world-aligned foot position / velocity / classical acceleration (gravity removed)
-};
-
+// Outputs leave the pass through a SINK (sk.tau(i, value), sk.foot(l, pos, vel, acc)) that stores straight into LDS,
+// so no lane holds an output array (dynamic indexing of per-lane arrays would go to scratch memory).
+// sin/cos of the 18 joint angles are computed ONCE per knot into LDS (cs/sn) and shared by every lane and pass.
 // link inertial constants (link frame, about COM): m, c, Ixx Ixy Ixz Iyy Iyz Izz  — sy = +1 left, -1 right
 
 template <class S>
@@ -64,10 +61,16 @@ HD void rev_joint(S c, S s, S qd, S qdd, V3<S>& om, V3<S>& vl, V3<S>& aa, V3<S>&
     om = o; vl = v; aa = a2; al = a1;
 }
 
-// One pass.  qs/vs/as: knot q(18), v(18), acceleration input(18) (LDS, broadcast reads); fext: 12 world foot forces.
-template <class S>
-HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const double* as, const double* fext, PassOut<S>& out) {
+template <class S> HD S mkt(double v, double t);
+template <> HD double mkt<double>(double v, double) { return v; }
+template <> HD Dual mkt<Dual>(double v, double t) { return Dual(v, t); }
+
+// One pass.  qs/vs/as: knot q(18), v(18), acceleration input(18); cs/sn: cos/sin of q (all LDS, broadcast reads);
+// fext: 12 world foot forces.
+template <class S, class SK>
+HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const double* as, const double* cs, const double* sn, const double* fext, const SK& out) {
     auto Q = [&](int i) { return mk<S>(qs[i], L.tq == i); };
+    auto SC = [&](int i, S& s_, S& c_) { const double c0 = cs[i], s0 = sn[i]; const bool sd = (L.tq == i); s_ = mkt<S>(s0, sd ? c0 : 0.0); c_ = mkt<S>(c0, sd ? -s0 : 0.0); };
     auto Vv = [&](int i) { return mk<S>(L.vscale * vs[i], L.tv == i); };
     auto Aa = [&](int i) { return S(L.aunit >= 0 ? (L.aunit == i ? 1.0 : 0.0) : L.ascale * as[i]); };
     const double ms = L.mscale;
@@ -76,7 +79,7 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
     V3<S> vl = {Vv(0), Vv(1), Vv(2)};
     V3<S> al = {Aa(0), Aa(1), Aa(2) + L.grav};
     S c3, s3, c4, s4, c5, s5;
-    sincos_(Q(3), s3, c3); sincos_(Q(4), s4, c4); sincos_(Q(5), s5, c5);
+    SC(3, s3, c3); SC(4, s4, c4); SC(5, s5, c5);
     rev_joint<2>(c3, s3, Vv(3), Aa(3), om, vl, aa, al);
     rev_joint<1>(c4, s4, Vv(4), Aa(4), om, vl, aa, al);
     rev_joint<0>(c5, s5, Vv(5), Aa(5), om, vl, aa, al);
@@ -88,7 +91,7 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
         const double sx = (l < 2) ? 1.0 : -1.0, sy = (l & 1) ? -1.0 : 1.0;
         const int j0 = 6 + 3 * l;
         S ca, sa, ch, sh, ck, sk;
-        sincos_(Q(j0), sa, ca); sincos_(Q(j0 + 1), sh, ch); sincos_(Q(j0 + 2), sk, ck);
+        SC(j0, sa, ca); SC(j0 + 1, sh, ch); SC(j0 + 2, sk, ck);
         // abad: origin (sx*.19, sy*.049, 0) in body, axis x
         V3<S> o1 = om, a1 = aa;
         V3<S> v1 = vl + crossc(om, sx * 0.19, sy * 0.049, 0.0), l1 = al + crossc(aa, sx * 0.19, sy * 0.049, 0.0);
@@ -116,16 +119,18 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
             w = rot<1>(ck, sk, w); w = rot<1>(ch, sh, w); w = rot<2>(L.cpsi, L.spsi, w); w = rot<0>(ca, sa, w);
             w = rot<0>(c5, s5, w); w = rot<1>(c4, s4, w); w = rot<2>(c3, s3, w); return w;
         };
-        out.fvel[l] = up(vp);
-        V3<S> aw = up(ap); aw.z = aw.z - L.grav; out.facc[l] = aw;
+        V3<S> vw = up(vp);
+        V3<S> aw = up(ap); aw.z = aw.z - L.grav;
+        V3<S> pw;
         {   // position: o_b + Rwb (p0a + Rx (p0h + Rz Ry (p0k + Ry r)))
             V3<S> w = {S(0.0), S(0.0), S(-0.195)};
             w = rot<1>(ck, sk, w); w.z = w.z - 0.209;
             w = rot<1>(ch, sh, w); w = rot<2>(L.cpsi, L.spsi, w); w.y = w.y + sy * 0.062;
             w = rot<0>(ca, sa, w); w.x = w.x + sx * 0.19; w.y = w.y + sy * 0.049;
             w = rot<0>(c5, s5, w); w = rot<1>(c4, s4, w); w = rot<2>(c3, s3, w);
-            out.fpos[l] = ob + w;
+            pw = ob + w;
         }
+        out.foot(l, pw, vw, aw);
         if (L.fscale != 0.0) {   // external world force at the foot -> shank coordinates, subtract
             V3<S> F = {S(L.fscale * fext[3 * l]), S(L.fscale * fext[3 * l + 1]), S(L.fscale * fext[3 * l + 2])};
             F = rotT<2>(c3, s3, F); F = rotT<1>(c4, s4, F); F = rotT<0>(c5, s5, F);
@@ -134,24 +139,24 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
             n3 = n3 - ccross(0.0, 0.0, -0.195, F);
         }
         // backward through the leg
-        out.tau[j0 + 2] = n3.y;
+        out.tau(j0 + 2, n3.y);
         V3<S> fu = rot<1>(ck, sk, f3), nu = rot<1>(ck, sk, n3);
         f2 = f2 + fu; n2 = n2 + nu + ccross(0.0, 0.0, -0.209, fu);
-        out.tau[j0 + 1] = n2.y;
+        out.tau(j0 + 1, n2.y);
         fu = rot<2>(L.cpsi, L.spsi, rot<1>(ch, sh, f2)); nu = rot<2>(L.cpsi, L.spsi, rot<1>(ch, sh, n2));
         f1 = f1 + fu; n1 = n1 + nu + ccross(0.0, sy * 0.062, 0.0, fu);
-        out.tau[j0] = n1.x;
+        out.tau(j0, n1.x);
         fu = rot<0>(ca, sa, f1); nu = rot<0>(ca, sa, n1);
         fb = fb + fu; nb = nb + nu + ccross(sx * 0.19, sy * 0.049, 0.0, fu);
     }
     // backward through the base
-    out.tau[5] = nb.x;
+    out.tau(5, nb.x);
     V3<S> f = rot<0>(c5, s5, fb), n = rot<0>(c5, s5, nb);
-    out.tau[4] = n.y;
+    out.tau(4, n.y);
     f = rot<1>(c4, s4, f); n = rot<1>(c4, s4, n);
-    out.tau[3] = n.z;
+    out.tau(3, n.z);
     f = rot<2>(c3, s3, f);
-    out.tau[0] = f.x; out.tau[1] = f.y; out.tau[2] = f.z;
+    out.tau(0, f.x); out.tau(1, f.y); out.tau(2, f.z);
 }
 
 }  // namespace hs

@@ -63,7 +63,7 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
 static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
 int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
     OptDev o = to_dev(*opt); SlotOut so{h->cost.data(), h->dsq.data(), h->ming.data(), h->maxh.data()};
-    static WbLds L;
+    static WbCore L;
     for (int b = 0; b < h->batch; b++) {
         h->fail[b] = 0;
         for (int s = 0; s < h->nslots; s++) {
@@ -78,7 +78,7 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
 }
 int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }
 int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
-    OptDev o = to_dev(*opt); static WbLds L;
+    OptDev o = to_dev(*opt); static WbLqLds L;
     for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
         int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
         if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
