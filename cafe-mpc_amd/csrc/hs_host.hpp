@@ -17,7 +17,8 @@ inline int constraint_group(const PhaseDev& P, int c) {
     return 3;
 }
 
-// Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes)
+// Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes);
+//             void replicate(void* base, size_t bytes_one, size_t count): copies record 0 into records 1..count-1
 template <class Mem>
 int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t* next, bool is_last, size_t B, PhaseDev& P, int slot0) {
     std::memset(&P, 0, sizeof(P));
@@ -68,7 +69,8 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     if (ng > 0) {
         std::vector<double> dl(hh * ng), ep(hh * ng);
         for (size_t k = 0; k < hh; k++) for (int c = 0; c < ng; c++) { int grp = constraint_group(P, c); dl[k * ng + c] = P.reb_init[grp][0]; ep[k * ng + c] = P.reb_init[grp][2]; }
-        for (size_t b = 0; b < B; b++) { mem.upload(P.delta + b * hh * ng, dl.data(), dl.size() * 8); mem.upload(P.eps + b * hh * ng, ep.data(), ep.size() * 8); }
+        mem.upload(P.delta, dl.data(), dl.size() * 8); mem.replicate(P.delta, dl.size() * 8, B);
+        mem.upload(P.eps, ep.data(), ep.size() * 8); mem.replicate(P.eps, ep.size() * 8, B);
     }
     if (P.nt > 0) { std::vector<double> sg(B * P.nt, P.al_init[0]), lm(B * P.nt, P.al_init[1]); mem.upload(P.sigma, sg.data(), sg.size() * 8); mem.upload(P.lambda, lm.data(), lm.size() * 8); }
     return HSDDP_OK;

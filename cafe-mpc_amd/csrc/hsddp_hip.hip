@@ -301,6 +301,12 @@ template <class T> static int dupload(hsddp_handle* h, const T** out, const T* s
     *out = p; return HSDDP_OK;
 }
 
+// record 0 -> records 1..count-1 by doubling device-to-device copies (log2(count) calls instead of `count`)
+static void dev_replicate(void* base, size_t one, size_t count) {
+    size_t have = 1;
+    while (have < count) { size_t n = std::min(have, count - have); hipMemcpy((char*)base + have * one, base, n * one, hipMemcpyDeviceToDevice); have += n; }
+}
+
 static OptDev to_dev(const hsddp_option_t& o) {
     OptDev d; d.alpha = o.alpha; d.gamma = o.gamma; d.update_penalty = o.update_penalty; d.update_relax = o.update_relax;
     d.update_regularization = o.update_regularization; d.update_ReB = o.update_ReB; d.max_DDP_iter = o.max_DDP_iter; d.max_AL_iter = o.max_AL_iter;
@@ -346,6 +352,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
         hsddp_handle* h;
         void* alloc(size_t bytes) { void* p = nullptr; bytes = std::max<size_t>(bytes, 8); if (hipMalloc(&p, bytes) != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed\n", bytes); return nullptr; } hipMemset(p, 0, bytes); h->allocs.push_back(p); return p; }
         void upload(void* dst, const void* src, size_t bytes) { hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+        void replicate(void* base, size_t one, size_t count) { dev_replicate(base, one, count); }
     } mem{h};
     for (int i = 0; i < n_phases && !rc; i++) {
         rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, h->ph[i], (int)sp.size());
@@ -378,9 +385,15 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     if (!h || phase < 0 || phase >= h->nph) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
     PhaseDev& P = h->ph[phase]; const size_t sx = (size_t)(P.h + 1) * 36, su = (size_t)P.h * 12, B = h->batch;
-    for (size_t b = 0; b < B; b++) {
-        if (Xbar) { const double* s = Xbar + (per_problem ? b * sx : 0); hipMemcpy(P.Xbar + b * sx, s, sx * 8, hipMemcpyHostToDevice); hipMemcpy(P.X + b * sx, s, sx * 8, hipMemcpyHostToDevice); }
-        if (Ubar) { const double* s = Ubar + (per_problem ? b * su : 0); hipMemcpy(P.Ubar + b * su, s, su * 8, hipMemcpyHostToDevice); hipMemcpy(P.U + b * su, s, su * 8, hipMemcpyHostToDevice); }
+    if (Xbar) {
+        HIPCK(hipMemcpy(P.Xbar, Xbar, (per_problem ? B : 1) * sx * 8, hipMemcpyHostToDevice));
+        if (!per_problem) dev_replicate(P.Xbar, sx * 8, B);
+        HIPCK(hipMemcpy(P.X, P.Xbar, B * sx * 8, hipMemcpyDeviceToDevice));
+    }
+    if (Ubar) {
+        HIPCK(hipMemcpy(P.Ubar, Ubar, (per_problem ? B : 1) * su * 8, hipMemcpyHostToDevice));
+        if (!per_problem) dev_replicate(P.Ubar, su * 8, B);
+        HIPCK(hipMemcpy(P.U, P.Ubar, B * su * 8, hipMemcpyDeviceToDevice));
     }
     HIPCK(hipMemset(P.K, 0, B * P.h * 432 * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
     return HSDDP_OK;

@@ -30,6 +30,7 @@ struct HostMem {
     hsddp_handle* h;
     void* alloc(size_t bytes) { void* p = calloc(bytes < 8 ? 8 : bytes, 1); h->allocs.push_back(p); return p; }
     void upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+    void replicate(void* base, size_t one, size_t count) { for (size_t i = 1; i < count; i++) memcpy((char*)base + i * one, base, one); }
 };
 
 extern "C" {

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Per-kernel timing through the step API (HIP events inside the library): rollout, LQ, Riccati sweep, linear rollout."""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--reps", type=int, default=3)
+a = ap.parse_args()
+pkg = ge.load_package()
+ph = pkg.problems.wb_trot_problem()
+s = pkg.MultiPhaseDDP(ph, batch=a.batch)
+s.set_initial_condition(pkg.problems.wb_ensemble_x0(a.batch, 1))
+opt = pkg.mhpc_ddp_setting()
+s.hybrid_rollout(0.0, opt); s.update_nominal_trajectory()
+for _ in range(a.reps):
+    s.LQ_approximation(opt); s.backward_sweep(0.0); s.linear_rollout(1.0, opt); s.hybrid_rollout(1.0, opt)
+kt = s.kernel_times()
+for k, (ms, n) in sorted(kt.items()):
+    print(f"{k:18s} {ms / n:10.3f} ms/launch  ({n} launches)")
