@@ -34,10 +34,21 @@ struct SweepLds {
     double dx[MAXN], dxn[MAXN], du[SW_M];
     double red[SW_NT];
     double dV1, dV2;
+    unsigned long long t_last;
     int ok;
 };
 
 #define CM(M, i, j, ld) (M)[(i) + (ld) * (j)]
+
+// optional in-kernel stamps (diagnostic builds only: -DSW_PROF): cycles per phase group, block 0 / thread 0
+#if defined(SW_PROF) && !defined(HS_HOST_EMU)
+__device__ unsigned long long g_sw_prof[16];
+#define SW_STAMP(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_sw_prof[i], t_ - S.t_last); S.t_last = t_; } }
+#define SW_STAMP0() { if (blockIdx.x == 0 && threadIdx.x == 0) S.t_last = clock64(); }
+#else
+#define SW_STAMP(i)
+#define SW_STAMP0()
+#endif
 
 // One 3x2 register tile of  C(i,j) (+)= alpha * sum_t opA(i,t) * B(t,j) ;  opA(i,t) = TA ? A[t + lda*i] : A[i + lda*t]
 template <bool TA>
@@ -77,6 +88,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
              if (tid == 0) { S.ok = 1; })
     for (int k = h - 1; k >= 0; k--) {
         const size_t kk = (size_t)b * h + k;
+        SW_STAMP0()
         HS_PHASE(NT,
             ld_mat<NT>(tid, S.A, LDN, P.A + kk * n * n, n, n); ld_mat<NT>(tid, S.Qxx, LDN, P.lxx + kk * n * n, n, n);
             ld_mat<NT>(tid, S.B, LDN, P.B + kk * n * m, n, m); ld_mat<NT>(tid, S.Quu, LDM, P.luu + kk * m * m, m, m);
@@ -87,6 +99,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
             }
             if (tid < n) { S.Qx[tid] = P.lx[kk * n + tid]; S.def[tid] = P.Defect[((size_t)b * (h + 1) + k + 1) * n + tid]; }
             if (tid < m) S.Qu[tid] = P.lu[kk * m + tid];)
+        SW_STAMP(0)
         // HA = H A ; HB = H B ; Gnext = G + H Defect[k+1] ; (p>0) lC = lyy C ; lD = lyy D
         {
             const int t1 = ntiles(n, n), t2 = t1 + ntiles(n, m), t3 = t2 + (p > 0 ? ntiles(p, n) : 0), t4 = t3 + (p > 0 ? ntiles(p, m) : 0);
@@ -99,6 +112,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
                 }
                 if (tid >= NT - n) { const int i = tid - (NT - n); double s = S.G[i]; for (int j = 0; j < n; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; })
         }
+        SW_STAMP(1)
         // Qxx += A^T HA (+ C^T lC) ; Qux = B^T HA (+ D^T lC) ; Quu += B^T HB (+ D^T lD) ; Qx += A^T Gn (+C^T ly) ; Qu += B^T Gn (+D^T ly)
         {
             const int t1 = ntiles(n, n), t2 = t1 + ntiles(m, n), t3 = t2 + ntiles(m, m);
@@ -118,6 +132,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
                     S.Qu[a] += s;
                 })
         }
+        SW_STAMP(2)
         // regularisation (also on Qxx: quirk x); store Qu / Quu / Qux as the reference keeps them (callers read them)
         HS_PHASE(NT,
             if (tid < n) CM(S.Qxx, tid, tid, LDN) += reg;
@@ -125,6 +140,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         HS_PHASE(NT,
             st_mat<NT>(tid, P.Quu + kk * m * m, S.Quu, LDM, m, m); st_mat<NT>(tid, P.Qux + kk * m * n, S.Qux, LDM, m, n);
             )
+        SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse, all inside one wave (no workgroup barrier)
         for (int j = 0; j < m; j++) {
             HS_WPHASE(if (tid >= j && tid < m) {
@@ -144,14 +160,17 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
             for (int i = 0; i < m; i++) { double s = (i == c) ? 1.0 : 0.0; for (int t = 0; t < i; t++) s -= S.LQ[i * LDM + t] * S.Qi[t * LDM + c]; S.Qi[i * LDM + c] = s / S.LQ[i * LDM + i]; }
             for (int i = m - 1; i >= 0; i--) { double s = S.Qi[i * LDM + c]; for (int t = i + 1; t < m; t++) s -= S.LQ[t * LDM + i] * S.Qi[t * LDM + c]; S.Qi[i * LDM + c] = s / S.LQ[i * LDM + i]; }
         })
+        SW_STAMP(4)
         // symmetrise Qxx (threads >= 64, wave 0 was busy) — pairs (i<j)
         HS_PHASE(NT,
             for (int e = tid; e < n * n; e += NT) { const int i = e % n, j = e / n; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
+        SW_STAMP(5)
         if (!S.ok) return false;
         // K = -Qi Qux ; dU = -Qi Qu
         HS_PHASE(NT,
             for (int tile = tid; tile < ntiles(m, n); tile += NT) mm_tile<false>(tile, S.K, LDM, S.Qi, LDM, S.Qux, LDM, m, m, false, -1.0);
             if (tid >= NT - m) { const int a = tid - (NT - m); double s = 0; for (int t = 0; t < m; t++) s += S.Qi[a * LDM + t] * S.Qu[t]; S.dU[a] = -s; })
+        SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE(NT,
             for (int tile = tid; tile < ntiles(n, n); tile += NT) {
@@ -162,7 +181,9 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
             if (tid >= NT - n) { const int i = tid - (NT - n); double s = S.Qx[i]; for (int t = 0; t < m; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * n + i] = s; }
             else if (tid == NT - n - 1) { double dVk = 0; for (int t = 0; t < m; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
             else if (tid >= NT - n - 1 - m && tid < NT - n - 1) { const int a = tid - (NT - n - 1 - m); P.dU[kk * m + a] = S.dU[a]; })
+        SW_STAMP(7)
         HS_PHASE(NT, st_mat<NT>(tid, P.K + kk * m * n, S.K, LDM, m, n);)
+        SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
     HS_PHASE(NT, if (tid < n) S.def[tid] = P.Defect[((size_t)b * (h + 1)) * n + tid];)

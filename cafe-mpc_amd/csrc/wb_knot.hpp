@@ -24,51 +24,85 @@ struct WbCore {
     double x[36], xb[36], u[12], acc[18], tau[18], fext[12], cs[18], sn[18];
     double M[18 * 18];                 // mass matrix (rollout: overwritten by its Cholesky factor)
     double h[18], Jall[12 * 18], Jdv[12], fpos[12], fvel[12];
-    double Jc[12 * 18], Xm[18 * 12];   // compact active Jacobian ; L^-1 Jc^T (rollout) or Minv Jc^T (LQ).  [Jc,Xm] doubles as K staging
-    double gam[12], G[144], LG[144];
-    double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64];
-    double gval[MAXG], bar[MAXG];
+    double JX[432];                    // Jc (12x18 compact active Jacobian) | Xm (18x12: L^-1 Jc^T or Minv Jc^T); also K / C staging
+    double gam[12];
+    double GG[432];                    // G (144) | LG (144) | gval (72) | bar (72); the LQ program reuses it for the foot acc / vel tangents
+    HD double* Jc() { return JX; }
+    HD double* Xm() { return JX + 216; }
+    HD double* G() { return GG; }
+    HD double* LG() { return GG + 144; }
+    HD double* gval() { return GG + 288; }
+    HD double* bar() { return GG + 360; }
+    HD double* dacc() { return GG; }          // LQ program: [3f+r][18] tangents of the foot accelerations
+    HD double* dvel() { return GG + 216; }    // LQ program: [3f+r][18] tangents of the foot velocities (= footVelPartialDq)
+    double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64], rdM[18], rdG[12];
 };
-struct WbDeriv {
-    double Lm[18 * 18], Minv[18 * 18], Ym[18 * 12], Lam[144];
-    double Kinv[30 * 30];
-    double W[36 * 64];                 // tangent columns [row][lane] (rows 0..17: d tau), later A / lxx staging
-    double dacc[12 * 18], dvel[12 * 18];   // foot acc / vel tangents of the 18 kinematic lanes: [3f+r][q index]
-    double Cst[12 * 36];
-    double JP[12 * 36], JW[12 * 36], wp[12], wv[12], ep[12], ev[12];
-    double bd[MAXG], bdd[MAXG];
+struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (see accessors)
+    double Minv[18 * 18];              // M^-1 ; later the barrier derivative tables bd / bdd
+    double Kinv[30 * 30];              // KKT inverse (padded) ; later the foot-cost Jacobian blocks JP / JW (2 x 12 x 36)
+    double W[18 * 54 + 18 * 36];       // before the tangent pass: Lm, Ym, Lam ; then T[18][54] tangent columns + R[18][36] result rows ;
+                                       // finally a dense 36x36 staging tile for lxx / Phixx
+    double wp[12], wv[12], ep[12], ev[12];
+    HD double* Lm() { return W; }
+    HD double* Ym() { return W + 324; }
+    HD double* Lam() { return W + 540; }
+    HD double* JP() { return Kinv; }
+    HD double* JW() { return Kinv + 432; }
+    HD double* bd() { return Minv; }
+    HD double* bdd() { return Minv + MAXG; }
 };
+constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
+// LQ-program aliases into WbCore: Cst = [Jc|Xm] (432), dacc = G.., dvel = G+216 (G,LG,gval,bar = 432)
 
-// ---- wave-cooperative dense helpers (row-major in LDS) -------------------------------------------------
-// Cholesky A = L L^T (lower), left-looking; Lo may alias A (in place).  tmp holds the column being built.
-template <int NT>
-HD void chol_lds(const double* A, double* Lo, int n, int ld, double* tmp, double diag_add) {
-    for (int j = 0; j < n; j++) {
-        HS_PHASE(NT, if (tid >= j && tid < n) {
-            double s = A[tid * ld + j] + ((tid == j) ? diag_add : 0.0);
-            for (int k = 0; k < j; k++) s -= Lo[tid * ld + k] * Lo[j * ld + k];
-            tmp[tid] = s;
-        })
-        HS_PHASE(NT, if (tid >= j && tid < n) {
-            double d = sqrt(tmp[j]);
-            Lo[tid * ld + j] = (tid == j) ? d : tmp[tid] / d;
+// ---- wave-cooperative dense helpers (row-major in LDS), COMPILE-TIME sizes ------------------------------
+// Every inner loop is fully unrolled and every private vector lives in registers: the serial recurrences of a
+// factorisation then depend only on FMA latency, not on an LDS round trip per step.
+// Cholesky A = L L^T (lower), one phase per column; Lo may alias A.  rd[i] = 1 / L[i][i].
+template <int NT, int N, int LD>
+HD void chol_s(const double* A, double* Lo, double* rd, double diag_add) {
+    _Pragma("unroll")
+    for (int j = 0; j < N; j++) {
+        HS_PHASE(NT, if (tid >= j && tid < N) {
+            double sj = A[j * LD + j] + diag_add, st = A[tid * LD + j];
+            _Pragma("unroll")
+            for (int k = 0; k < j; k++) { const double ljk = Lo[j * LD + k]; sj -= ljk * ljk; st -= Lo[tid * LD + k] * ljk; }
+            const double d = sqrt(sj);
+            // the diagonal of Lo is never written (it may alias A, whose pivot other lanes still read) nor read: rd[] carries it
+            if (tid == j) rd[j] = 1.0 / d; else Lo[tid * LD + j] = st / d;
         })
     }
 }
-// column c of the inverse from a Cholesky factor, written into Inv[:, c] (row-major ld). Called by lane c.
-HD void chol_inv_col(const double* Lo, double* Inv, int n, int ld, int c) {
-    for (int i = 0; i < n; i++) {
-        double s = (i == c) ? 1.0 : 0.0;
-        for (int k = 0; k < i; k++) s -= Lo[i * ld + k] * Inv[k * ld + c];
-        Inv[i * ld + c] = s / Lo[i * ld + i];
-    }
-    for (int i = n - 1; i >= 0; i--) {
-        double s = Inv[i * ld + c];
-        for (int k = i + 1; k < n; k++) s -= Lo[k * ld + i] * Inv[k * ld + c];
-        Inv[i * ld + c] = s / Lo[i * ld + i];
+// x = L^-1 b (forward) in registers; b/x are private arrays
+template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, double* x) {
+    _Pragma("unroll")
+    for (int i = 0; i < N; i++) {
+        double s = x[i];
+        _Pragma("unroll")
+        for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * x[k];
+        x[i] = s * rd[i];
     }
 }
+// x = L^-T b (backward) in registers
+template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, double* x) {
+    _Pragma("unroll")
+    for (int i = N - 1; i >= 0; i--) {
+        double s = x[i];
+        _Pragma("unroll")
+        for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * x[k];
+        x[i] = s * rd[i];
+    }
+}
+// column c of (L L^T)^-1 into Inv[:, c] (row-major ldi). Called by lane c.
+template <int N, int LD> HD void inv_col_s(const double* Lo, const double* rd, double* Inv, int ldi, int c) {
+    double y[N];
+    _Pragma("unroll")
+    for (int i = 0; i < N; i++) y[i] = (i == c) ? 1.0 : 0.0;
+    fwd_s<N, LD>(Lo, rd, y); bwd_s<N, LD>(Lo, rd, y);
+    _Pragma("unroll")
+    for (int i = 0; i < N; i++) Inv[i * ldi + c] = y[i];
+}
+
 
 HD LaneCfg lane_cfg(const ModelDev& md, bool kin, double mscale, double grav, double fscale, double vscale, double ascale, int aunit, int tq, int tv) {
     LaneCfg c;
@@ -91,13 +125,13 @@ struct PSink {   // value pass: lanes 0..17 -> column `lane` of M and of all foo
     }
 };
 struct DSink {   // tangent pass: d tau -> W[i][lane]; kinematic lanes (>=36) also store foot acc / vel tangents
-    WbDeriv* D; int lane;
-    HD void tau(int i, const Dual& v) const { D->W[i * 64 + lane] = v.d; }
+    WbDeriv* D; WbCore* C; int lane;
+    HD void tau(int i, const Dual& v) const { D->W[i * WT + lane] = v.d; }
     HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>& a) const {
         if (lane >= 36) {
             const int j = lane - 36;
-            D->dacc[(3 * f) * 18 + j] = a.x.d; D->dacc[(3 * f + 1) * 18 + j] = a.y.d; D->dacc[(3 * f + 2) * 18 + j] = a.z.d;
-            D->dvel[(3 * f) * 18 + j] = v.x.d; D->dvel[(3 * f + 1) * 18 + j] = v.y.d; D->dvel[(3 * f + 2) * 18 + j] = v.z.d;
+            C->dacc()[(3 * f) * 18 + j] = a.x.d; C->dacc()[(3 * f + 1) * 18 + j] = a.y.d; C->dacc()[(3 * f + 2) * 18 + j] = a.z.d;
+            C->dvel()[(3 * f) * 18 + j] = v.x.d; C->dvel()[(3 * f + 1) * 18 + j] = v.y.d; C->dvel()[(3 * f + 2) * 18 + j] = v.z.d;
         }
     }
 };
@@ -117,14 +151,29 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
     })
 }
 
-// compact active Jacobian + drift  (mode 0: gam = Jdot v + 2 alpha J v ; mode 1: 0)
+// compact active Jacobian + drift, PADDED to 12 rows (rows >= 3*nc are zero) so that every later loop has a
+// compile-time trip count (mode 0: gam = Jdot v + 2 alpha J v ; mode 1: 0)
 template <int NT>
 HD void wb_select(WbCore& L, int nc, const int* feet, int mode, double alpha) {
-    HS_PHASE(NT, if (tid < 3 * nc) {
-        const int f = feet[tid / 3], r = tid % 3;
-        for (int j = 0; j < 18; j++) L.Jc[tid * 18 + j] = L.Jall[(3 * f + r) * 18 + j];
-        L.gam[tid] = (mode == 0) ? (L.Jdv[3 * f + r] + 2.0 * alpha * L.fvel[3 * f + r]) : 0.0;
-    } if (tid < 12) { L.grf[tid] = 0.0; L.lam[tid] = 0.0; })
+    HS_PHASE(NT, if (tid < 12) {
+        const bool act = tid < 3 * nc;
+        const int f = act ? feet[tid / 3] : 0, r = tid % 3;
+        _Pragma("unroll")
+        for (int j = 0; j < 18; j++) L.Jc()[tid * 18 + j] = act ? L.Jall[(3 * f + r) * 18 + j] : 0.0;
+        L.gam[tid] = (act && mode == 0) ? (L.Jdv[3 * f + r] + 2.0 * alpha * L.fvel[3 * f + r]) : 0.0;
+        L.grf[tid] = 0.0;
+    })
+}
+// G = X^T X (12x12, padded rows/cols get the identity) and rhs; X = Xm (18x12)
+HD void wb_gram(WbCore& L, int m, int tid, double rhs_dot) {
+    _Pragma("unroll")
+    for (int a = 0; a < 12; a++) {
+        double s = 0;
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.Xm()[i * 12 + tid];
+        L.G()[a * 12 + tid] = (tid >= m || a >= m) ? ((a == tid) ? 1.0 : 0.0) : s;
+    }
+    L.rhs[tid] = (tid < m) ? (-rhs_dot - L.gam[tid]) : 0.0;
 }
 
 // Contact solve WITHOUT forming M^-1 (rollout): M = L L^T in place, X = L^-1 Jc^T, G = X^T X (+damping),
@@ -134,76 +183,103 @@ template <int NT>
 HD void wb_kkt_direct(WbCore& L, int nc, const int* feet, int mode, double alpha) {
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
-    chol_lds<NT>(L.M, L.M, 18, 18, L.tmp, 0.0);
-    HS_PHASE(NT, if (tid < m) {              // X[:, tid] = L^-1 Jc[tid, :]^T
-        for (int i = 0; i < 18; i++) { double s = L.Jc[tid * 18 + i]; for (int k = 0; k < i; k++) s -= L.M[i * 18 + k] * L.Xm[k * 12 + tid]; L.Xm[i * 12 + tid] = s / L.M[i * 18 + i]; }
-    } else if (tid == 63) {                  // y = L^-1 r  (mode 0)
-        for (int i = 0; i < 18; i++) {
-            double s = (mode == 0) ? (L.tau[i] - L.h[i]) : 0.0;
-            for (int k = 0; k < i; k++) s -= L.M[i * 18 + k] * L.a0[k];
-            L.a0[i] = s / L.M[i * 18 + i];
-        }
+    chol_s<NT, 18, 18>(L.M, L.M, L.rdM, 0.0);
+    HS_PHASE(NT, if (tid < 12) {             // X[:, tid] = L^-1 Jc[tid, :]^T
+        double x[18];
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) x[i] = L.Jc()[tid * 18 + i];
+        fwd_s<18, 18>(L.M, L.rdM, x);
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) L.Xm()[i * 12 + tid] = x[i];
+    } else if (tid == 63) {                  // y = L^-1 (tau - h)  (mode 0) ; 0 (mode 1)
+        double y[18];
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) y[i] = (mode == 0) ? (L.tau[i] - L.h[i]) : 0.0;
+        fwd_s<18, 18>(L.M, L.rdM, y);
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) L.a0[i] = y[i];
     })
-    if (m > 0) {
-        HS_PHASE(NT, if (tid < m) {
-            for (int a = 0; a < m; a++) { double s = 0; for (int i = 0; i < 18; i++) s += L.Xm[i * 12 + a] * L.Xm[i * 12 + tid]; L.G[a * 12 + tid] = s; }
-            double s = 0;
-            if (mode == 0) { for (int i = 0; i < 18; i++) s += L.Xm[i * 12 + tid] * L.a0[i]; }
-            else { for (int i = 0; i < 18; i++) s += L.Jc[tid * 18 + i] * L.x[18 + i]; }
-            L.rhs[tid] = -s - L.gam[tid];
-        })
-        chol_lds<NT>(L.G, L.LG, m, 12, L.tmp, (mode == 0) ? 1e-12 : 0.0);
-        HS_PHASE(NT, if (tid == 0) {
-            for (int i = 0; i < m; i++) { double s = L.rhs[i]; for (int k = 0; k < i; k++) s -= L.LG[i * 12 + k] * L.lam[k]; L.lam[i] = s / L.LG[i * 12 + i]; }
-            for (int i = m - 1; i >= 0; i--) { double s = L.lam[i]; for (int k = i + 1; k < m; k++) s -= L.LG[k * 12 + i] * L.lam[k]; L.lam[i] = s / L.LG[i * 12 + i]; }
-        })
-    }
-    HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; for (int a = 0; a < m; a++) s += L.Xm[tid * 12 + a] * L.lam[a]; L.tmp[tid] = s; }
-             if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = L.lam[tid];)
-    HS_PHASE(NT, if (tid == 0) {             // back substitution L^T z = tmp
-        for (int i = 17; i >= 0; i--) { double s = L.tmp[i]; for (int k = i + 1; k < 18; k++) s -= L.M[k * 18 + i] * L.qdd[k]; L.qdd[i] = s / L.M[i * 18 + i]; }
-        if (mode == 1) for (int i = 0; i < 18; i++) L.qdd[i] += L.x[18 + i];
+    HS_PHASE(NT, if (tid < 12) {
+        double s = 0;
+        if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + tid] * L.a0[i]; }
+        else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[tid * 18 + i] * L.x[18 + i]; }
+        wb_gram(L, m, tid, s);
+    })
+    chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    HS_PHASE(NT, if (tid == 0) {             // lam = G^-1 rhs ; then z = y + X lam ; back substitution L^T qdd = z
+        double lam[12];
+        _Pragma("unroll")
+        for (int i = 0; i < 12; i++) lam[i] = L.rhs[i];
+        fwd_s<12, 12>(L.LG(), L.rdG, lam); bwd_s<12, 12>(L.LG(), L.rdG, lam);
+        double z[18];
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) { double s = L.a0[i]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[i * 12 + a] * lam[a]; z[i] = s; }
+        bwd_s<18, 18>(L.M, L.rdM, z);
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) L.qdd[i] = z[i] + ((mode == 1) ? L.x[18 + i] : 0.0);
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
     })
 }
 
-// Contact solve WITH M^-1 and the KKT-matrix inverse (LQ).  Kinv: (18+m)^2, ld 30 (Pinocchio
-// computeKKTContactDynamicMatrixInverse / getKKTContactDynamicMatrixInverse, damping 0).
+// Contact solve WITH M^-1 and the KKT-matrix inverse (LQ).  Kinv: 30x30 (ld 30), padded rows/cols are zero
+// (Pinocchio computeKKTContactDynamicMatrixInverse / getKKTContactDynamicMatrixInverse, damping 0).
 template <int NT>
 HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, double alpha) {
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
-    chol_lds<NT>(L.M, D.Lm, 18, 18, L.tmp, 0.0);
-    HS_PHASE(NT, if (tid < 18) chol_inv_col(D.Lm, D.Minv, 18, 18, tid);)
+    chol_s<NT, 18, 18>(L.M, D.Lm(), L.rdM, 0.0);
+    HS_PHASE(NT, if (tid < 18) inv_col_s<18, 18>(D.Lm(), L.rdM, D.Minv, 18, tid);)
     HS_PHASE(NT, if (tid < 18) {
         double s = 0;
-        if (mode == 0) { for (int j = 0; j < 18; j++) s += D.Minv[tid * 18 + j] * (L.tau[j] - L.h[j]); } else s = L.x[18 + tid];
+        if (mode == 0) { _Pragma("unroll") for (int j = 0; j < 18; j++) s += D.Minv[tid * 18 + j] * (L.tau[j] - L.h[j]); } else s = L.x[18 + tid];
         L.a0[tid] = s;
+    } else if (tid >= 32 && tid < 44) {      // X[:, a] = Minv Jc[a, :]^T
+        const int a = tid - 32;
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) { double s = 0; _Pragma("unroll") for (int j = 0; j < 18; j++) s += D.Minv[i * 18 + j] * L.Jc()[a * 18 + j]; L.Xm()[i * 12 + a] = s; }
     })
-    if (m > 0) {
-        HS_PHASE(NT, if (tid < m) {
-            for (int i = 0; i < 18; i++) { double s = 0; for (int j = 0; j < 18; j++) s += D.Minv[i * 18 + j] * L.Jc[tid * 18 + j]; L.Xm[i * 12 + tid] = s; }
-            for (int a = 0; a < m; a++) { double s = 0; for (int i = 0; i < 18; i++) s += L.Jc[a * 18 + i] * L.Xm[i * 12 + tid]; L.G[a * 12 + tid] = s; }
-            double s = 0; for (int i = 0; i < 18; i++) s += L.Jc[tid * 18 + i] * L.a0[i];
-            L.rhs[tid] = -s - L.gam[tid];
-        })
-        chol_lds<NT>(L.G, L.LG, m, 12, L.tmp, (mode == 0) ? 1e-12 : 0.0);
-        HS_PHASE(NT, if (tid == 0) {
-            for (int i = 0; i < m; i++) { double s = L.rhs[i]; for (int k = 0; k < i; k++) s -= L.LG[i * 12 + k] * L.lam[k]; L.lam[i] = s / L.LG[i * 12 + i]; }
-            for (int i = m - 1; i >= 0; i--) { double s = L.lam[i]; for (int k = i + 1; k < m; k++) s -= L.LG[k * 12 + i] * L.lam[k]; L.lam[i] = s / L.LG[i * 12 + i]; }
-        })
-    }
-    HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; for (int a = 0; a < m; a++) s += L.Xm[tid * 12 + a] * L.lam[a]; L.qdd[tid] = s; }
-             if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = L.lam[tid];)
-    if (m > 0) {
-        if (mode == 0) chol_lds<NT>(L.G, L.LG, m, 12, L.tmp, 0.0);
-        HS_PHASE(NT, if (tid < m) chol_inv_col(L.LG, D.Lam, m, 12, tid);)
-        HS_PHASE(NT, if (tid < m) { for (int i = 0; i < 18; i++) { double s = 0; for (int b = 0; b < m; b++) s += L.Xm[i * 12 + b] * D.Lam[b * 12 + tid]; D.Ym[i * 12 + tid] = s; } })
-    }
+    HS_PHASE(NT, if (tid < 12) {
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) {       // G = Jc Minv Jc^T
+            double s = 0;
+            _Pragma("unroll")
+            for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.Xm()[i * 12 + tid];
+            L.G()[a * 12 + tid] = (tid >= m || a >= m) ? ((a == tid) ? 1.0 : 0.0) : s;
+        }
+        double s = 0;
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) s += L.Jc()[tid * 18 + i] * L.a0[i];
+        L.rhs[tid] = (tid < m) ? (-s - L.gam[tid]) : 0.0;
+    })
+    chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    HS_PHASE(NT, if (tid == 0) {
+        double lam[12];
+        _Pragma("unroll")
+        for (int i = 0; i < 12; i++) lam[i] = L.rhs[i];
+        fwd_s<12, 12>(L.LG(), L.rdG, lam); bwd_s<12, 12>(L.LG(), L.rdG, lam);
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
+    })
+    HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[tid * 12 + a] * L.lam[a]; L.qdd[tid] = s; })
+    if (mode == 0) chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, 0.0);      // undamped factor for the KKT inverse
+    HS_PHASE(NT, if (tid < 12) inv_col_s<12, 12>(L.LG(), L.rdG, D.Lam(), 12, tid);)
+    HS_PHASE(NT, if (tid < 12) {             // Y = X Lam with padded rows/cols of Lam forced to zero
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) { double s = 0; _Pragma("unroll") for (int b = 0; b < 12; b++) s += L.Xm()[i * 12 + b] * D.Lam()[b * 12 + tid]; D.Ym()[i * 12 + tid] = (tid < m) ? s : 0.0; }
+    })
     HS_PHASE(NT, if (tid < 18) {
-        for (int i = 0; i < 18; i++) { double s = D.Minv[i * 18 + tid]; for (int a = 0; a < m; a++) s -= D.Ym[i * 12 + a] * L.Xm[tid * 12 + a]; D.Kinv[i * 30 + tid] = s; }
-        for (int a = 0; a < m; a++) { D.Kinv[(18 + a) * 30 + tid] = D.Ym[tid * 12 + a]; D.Kinv[tid * 30 + 18 + a] = D.Ym[tid * 12 + a]; }
-    } else if (tid >= 18 && tid < 18 + m) { const int a = tid - 18; for (int b = 0; b < m; b++) D.Kinv[(18 + b) * 30 + 18 + a] = -D.Lam[b * 12 + a]; })
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) { double s = D.Minv[i * 18 + tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s -= D.Ym()[i * 12 + a] * L.Xm()[tid * 12 + a]; D.Kinv[i * 30 + tid] = s; }
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) { D.Kinv[(18 + a) * 30 + tid] = D.Ym()[tid * 12 + a]; D.Kinv[tid * 30 + 18 + a] = D.Ym()[tid * 12 + a]; }
+    } else if (tid >= 32 && tid < 44) {
+        const int a = tid - 32;
+        _Pragma("unroll")
+        for (int b = 0; b < 12; b++) D.Kinv[(18 + b) * 30 + 18 + a] = (a < m && b < m) ? -D.Lam()[b * 12 + a] : 0.0;
+    })
 }
+
 
 // Tangent pass: lanes 0..35: d ID(q,v,acc)/dx_lane (psi_dyn, gravity `grav`); lanes 36..53: massless, foot forces L.fext,
 // psi_kin, tangent on q_(lane-36): tau tangent = -d(J^T F)/dq, foot acc / vel tangents.
@@ -212,7 +288,7 @@ HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double 
     HS_PHASE(NT, if (tid < 54 && !(q_only && tid >= 18 && tid < 36)) {
         LaneCfg c = (tid < 36) ? lane_cfg(md, false, 1.0, grav, 0.0, vscale_dyn, 1.0, -1, tid < 18 ? tid : -1, tid >= 18 ? tid - 18 : -1)
                                : lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, tid - 36, -1);
-        DSink sk{&D, tid};
+        DSink sk{&D, &L, tid};
         wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
     })
 }
@@ -268,7 +344,7 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
                         const double* x0, SlotOut so, size_t slot, int* fail_flag) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12;
-    double* Kst = L.Jc;   // 432 doubles: [Jc | Xm] are free until the contact solve
+    double* Kst = L.Jc();   // 432 doubles: [Jc | Xm] are free until the contact solve
     HS_PHASE(NT, if (tid < 36) {
         double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid];
         L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
@@ -293,9 +369,9 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
     } if (tid < 12) P.Y[((size_t)b * h + k) * 12 + tid] = L.grf[tid];)
     // constraints + barrier
     HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
-        double g = wb_constraint(P, L, c); L.gval[c] = g;
+        double g = wb_constraint(P, L, c); L.gval()[c] = g;
         size_t gi = ((size_t)b * h + k) * P.ng + c; P.g[gi] = g;
-        L.bar[c] = P.eps[gi] * reb_barrier(g, P.delta[gi]);
+        L.bar()[c] = P.eps[gi] * reb_barrier(g, P.delta[gi]);
     })
     HS_PHASE(NT, if (tid == 0) {
         double lb = wb_running_cost_base(P, L, k);
@@ -303,10 +379,10 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
         double l = lb;
         if (reb_active) {   // per constraint object: ReB_cost then l += dt*ReB_cost (SinglePhase.cpp:394-402)
             int offs[4] = {P.go_torque, P.go_joint, P.go_height, P.go_grf}; int sz[4] = {24, 24, 1, 5 * P.nc};
-            for (int gI = 0; gI < 4; gI++) if (offs[gI] >= 0) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += L.bar[offs[gI] + i]; l += P.dt * c; }
+            for (int gI = 0; gI < 4; gI++) if (offs[gI] >= 0) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i]; l += P.dt * c; }
         }
         P.l[(size_t)b * h + k] = l;
-        double ming = 0; for (int c = 0; c < P.ng; c++) ming = fmin(ming, L.gval[c]);
+        double ming = 0; for (int c = 0; c < P.ng; c++) ming = fmin(ming, L.gval()[c]);
         double dsq = 0, nsq = 0; for (int i = 0; i < 36; i++) { dsq += L.red[i]; nsq += L.tmp[i]; }
         so.cost[slot] = l; so.dsq[slot] = dsq; so.ming[slot] = ming; so.maxh[slot] = 0.0;
         if (sqrt(nsq) > 1e6 || !(nsq == nsq)) fail_flag[b] = 1;   // SinglePhase.cpp:205
@@ -383,8 +459,8 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
     HS_PHASE(NT,
         for (int e = tid; e < 432; e += NT) {
             const int r = e / 36, c = e % 36;
-            D.JP[e] = (c >= 3 && c < 18) ? L.Jall[r * 18 + c] : 0.0;
-            D.JW[e] = (c < 18) ? D.dvel[r * 18 + c] : L.Jall[r * 18 + c - 18];
+            D.JP()[e] = (c >= 3 && c < 18) ? L.Jall[r * 18 + c] : 0.0;
+            D.JW()[e] = (c < 18) ? L.dvel()[r * 18 + c] : L.Jall[r * 18 + c - 18];
         }
         if (tid < 12) {
             const int f = tid / 3, a = tid % 3;
@@ -403,18 +479,18 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
         })
 }
 // column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  added to out[0..35], and the gradient entry
-HD double wb_cost_column(const WbDeriv& D, int d, double* colout /* stride 64 */) {
+HD double wb_cost_column(WbDeriv& D, int d, double* colout /* stride 36 */) {
     double tp[12], tw[12];
         _Pragma("unroll")
-    for (int r = 0; r < 12; r++) { tp[r] = D.wp[r] * D.JP[r * 36 + d]; tw[r] = D.wv[r] * D.JW[r * 36 + d]; }
+    for (int r = 0; r < 12; r++) { tp[r] = D.wp[r] * D.JP()[r * 36 + d]; tw[r] = D.wv[r] * D.JW()[r * 36 + d]; }
     double g = 0;
         _Pragma("unroll")
     for (int r = 0; r < 12; r++) g += tp[r] * D.ep[r] + tw[r] * D.ev[r];
     for (int i = 0; i < 36; i++) {
         double s = 0;
         _Pragma("unroll")
-        for (int r = 0; r < 12; r++) s += D.JP[r * 36 + i] * tp[r] + D.JW[r * 36 + i] * tw[r];
-        colout[i * 64] += s;
+        for (int r = 0; r < 12; r++) s += D.JP()[r * 36 + i] * tp[r] + D.JW()[r * 36 + i] * tw[r];
+        colout[i * 36] += s;
     }
     return g;
 }
@@ -438,14 +514,14 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         const int d = tid;
         double top[18], bot[12];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = D.W[i * 64 + d] + ((d < 18) ? D.W[i * 64 + 36 + d] : 0.0);   // lanes 36+: tau tangent = -dJTF
+        for (int i = 0; i < 18; i++) top[i] = D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0);   // lanes 36+: tau tangent = -dJTF
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) {
             bot[a] = 0.0;
             if (a < m) {
                 const int r = 3 * P.feet[a / 3] + a % 3;
-                if (d < 18) bot[a] = D.dacc[r * 18 + d] + 2.0 * P.bg_alpha * D.dvel[r * 18 + d];
-                else bot[a] = 2.0 * D.dvel[r * 18 + (d - 18)] + 2.0 * P.bg_alpha * L.Jall[r * 18 + (d - 18)];   // footAccPartialDv == 2 footVelPartialDq
+                if (d < 18) bot[a] = L.G()[r * 18 + d] + 2.0 * P.bg_alpha * L.dvel()[r * 18 + d];
+                else bot[a] = 2.0 * L.dvel()[r * 18 + (d - 18)] + 2.0 * P.bg_alpha * L.Jall[r * 18 + (d - 18)];   // footAccPartialDv == 2 footVelPartialDq
             }
         }
         for (int i = 0; i < 18; i++) {     // rows 18..35 of A, kept in W rows 18..35
@@ -453,25 +529,25 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         _Pragma("unroll")
             for (int j = 0; j < 18; j++) s -= D.Kinv[i * 30 + j] * top[j];
         _Pragma("unroll")
-            for (int a = 0; a < 12; a++) if (a < m) s -= D.Kinv[i * 30 + 18 + a] * bot[a];     // Kinv columns >= 18+m are never written
-            D.W[(18 + i) * 64 + d] = s * dt + ((d == 18 + i) ? 1.0 : 0.0);
+            for (int a = 0; a < 12; a++) s -= D.Kinv[i * 30 + 18 + a] * bot[a];     // padded columns of Kinv are zero
+            D.W[WR0 + i * 36 + d] = s * dt + ((d == 18 + i) ? 1.0 : 0.0);
         }
-        for (int a = 0; a < 12; a++) D.Cst[a + 12 * d] = 0.0;
+        for (int a = 0; a < 12; a++) L.Jc()[a + 12 * d] = 0.0;
         for (int a = 0; a < m; a++) {
             double s = 0;
         _Pragma("unroll")
             for (int j = 0; j < 18; j++) s += D.Kinv[(18 + a) * 30 + j] * top[j];
         _Pragma("unroll")
-            for (int b2 = 0; b2 < 12; b2++) if (b2 < m) s += D.Kinv[(18 + a) * 30 + 18 + b2] * bot[b2];
-            D.Cst[(3 * P.feet[a / 3] + a % 3) + 12 * d] = s;
+            for (int b2 = 0; b2 < 12; b2++) s += D.Kinv[(18 + a) * 30 + 18 + b2] * bot[b2];
+            L.Jc()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = s;
         }
     })
     // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
     HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) {
         const int r = e % 36, c = e / 36;
-        P.A[kk * 1296 + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[r * 64 + c];
+        P.A[kk * 1296 + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
     })
-    store_block<NT>(P.C + kk * 432, D.Cst, 432);
+    store_block<NT>(P.C + kk * 432, L.Jc(), 432);
     HS_PHASE(NT,
         for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * 432 + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
         for (int e = tid; e < 144; e += NT) { const int r = e % 12, j = e / 12, f = r / 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = 3 * t + r % 3;
@@ -481,8 +557,8 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
         size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
         if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
-        D.bd[c] = reb_active ? e * bd : 0.0; D.bdd[c] = reb_active ? e * bdd : 0.0;
-    } for (int e = tid; e < 36 * 64; e += NT) D.W[e] = 0.0;)
+        D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
+    } for (int e = tid; e < 1296; e += NT) D.W[e] = 0.0;)
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
         double lxd = dt * P.q[d] * (L.x[d] - P.xr[(size_t)k * 36 + d]);
@@ -491,20 +567,20 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         // ReB fold on x (joint limits: x[6+i], height: x[2]) — rank-1 updates on the diagonal (ConstraintsBase.h:282-287)
         if (P.go_joint >= 0 && d >= 6 && d < 18) {
             const int i = d - 6;
-            lxd += dt * (D.bd[P.go_joint + i] - D.bd[P.go_joint + 12 + i]); diag += dt * (D.bdd[P.go_joint + i] + D.bdd[P.go_joint + 12 + i]);
+            lxd += dt * (D.bd()[P.go_joint + i] - D.bd()[P.go_joint + 12 + i]); diag += dt * (D.bdd()[P.go_joint + i] + D.bdd()[P.go_joint + 12 + i]);
         }
-        if (P.go_height >= 0 && d == 2) { lxd += dt * D.bd[P.go_height]; diag += dt * D.bdd[P.go_height]; }
-        D.W[d * 64 + d] += diag;
+        if (P.go_height >= 0 && d == 2) { lxd += dt * D.bd()[P.go_height]; diag += dt * D.bdd()[P.go_height]; }
+        D.W[d * 36 + d] += diag;
         P.lx[kk * 36 + d] = lxd;
     })
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * 1296 + e] = D.W[r * 64 + c]; })
+    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * 1296 + e] = D.W[r * 36 + c]; })
     // lu, luu (diag + torque barrier), ly, lyy (grf barrier 3x3 blocks) staged in Cst (288 of 432)
-    HS_PHASE(NT, for (int i = tid; i < 288; i += NT) D.Cst[i] = 0.0;)
+    HS_PHASE(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
     HS_PHASE(NT, if (tid < 12) {
         const int i = tid;
         double lu = dt * P.r[i] * (L.u[i] - P.ur[(size_t)k * 12 + i]), luu = dt * P.r[i];
-        if (P.go_torque >= 0) { lu += dt * (-D.bd[P.go_torque + i] + D.bd[P.go_torque + 12 + i]); luu += dt * (D.bdd[P.go_torque + i] + D.bdd[P.go_torque + 12 + i]); }
-        P.lu[kk * 12 + i] = lu; D.Cst[i + 12 * i] = luu;
+        if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }
+        P.lu[kk * 12 + i] = lu; L.Jc()[i + 12 * i] = luu;
         // y: grf pyramid rows [0 0 1; -1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu] for foot f = i/3
         double ly = 0.0; const int f = i / 3, r = i % 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = t;
         if (P.go_grf >= 0 && a >= 0) {
@@ -512,15 +588,15 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
             for (int c = 0; c < 5; c++) {
                 const double r0 = (c == 1) ? -1.0 : (c == 2) ? 1.0 : 0.0, r1 = (c == 3) ? -1.0 : (c == 4) ? 1.0 : 0.0, r2 = (c == 0) ? 1.0 : mu;
                 const double rr = (r == 0) ? r0 : (r == 1) ? r1 : r2;
-                const double hb = dt * D.bdd[P.go_grf + 5 * a + c] * rr;
-                ly += D.bd[P.go_grf + 5 * a + c] * rr;
-                D.Cst[144 + (3 * f) + 12 * i] += hb * r0; D.Cst[144 + (3 * f + 1) + 12 * i] += hb * r1; D.Cst[144 + (3 * f + 2) + 12 * i] += hb * r2;
+                const double hb = dt * D.bdd()[P.go_grf + 5 * a + c] * rr;
+                ly += D.bd()[P.go_grf + 5 * a + c] * rr;
+                L.Jc()[144 + (3 * f) + 12 * i] += hb * r0; L.Jc()[144 + (3 * f + 1) + 12 * i] += hb * r1; L.Jc()[144 + (3 * f + 2) + 12 * i] += hb * r2;
             }
         }
         P.ly[kk * 12 + i] = dt * ly;
     })
-    store_block<NT>(P.luu + kk * 144, D.Cst, 144);
-    store_block<NT>(P.lyy + kk * 144, D.Cst + 144, 144);
+    store_block<NT>(P.luu + kk * 144, L.Jc(), 144);
+    store_block<NT>(P.lyy + kk * 144, L.Jc() + 144, 144);
 }
 
 // Terminal partials of a phase (+ AL) and the reset-map partial Px (next_n x 36, column-major) if a phase follows.
@@ -534,7 +610,7 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     // d(J v)/dq with psi_kin at (q, v): kinematic lanes only
     wb_dpass<NT>(L, D, md, 0.0, 1.0, 1.0, 0.0, true);
     wb_cost_blocks<NT>(S, P, h, true);
-    HS_PHASE(NT, for (int e = tid; e < 36 * 64; e += NT) D.W[e] = 0.0;)
+    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) D.W[e] = 0.0;)
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
         double px = P.qf[d] * (L.x[d] - P.xr[(size_t)h * 36 + d]);
@@ -546,14 +622,14 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
                 const double sg = P.sigma[(size_t)b * P.nt + t], lm = P.lambda[(size_t)b * P.nt + t], hh = P.th[(size_t)b * P.nt + t];
                 const double hd = d < 18 ? L.Jall[(3 * f + 2) * 18 + d] : 0.0;
                 px += (sg * hh + lm) * hd;
-                for (int i = 0; i < 18; i++) D.W[i * 64 + d] += (sg * (1 + hh) + lm) * (L.Jall[(3 * f + 2) * 18 + i] * hd);
+                for (int i = 0; i < 18; i++) D.W[i * 36 + d] += (sg * (1 + hh) + lm) * (L.Jall[(3 * f + 2) * 18 + i] * hd);
                 t++;
             }
         }
-        D.W[d * 64 + d] += diag;
+        D.W[d * 36 + d] += diag;
         P.Phix[(size_t)b * 36 + d] = px;
     })
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.Phixx[(size_t)b * 1296 + e] = D.W[r * 64 + c]; })
+    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.Phixx[(size_t)b * 1296 + e] = D.W[r * 36 + c]; })
     if (Pn == nullptr) return;
     const int nn = Pn->n;
     if (!P.has_impact) {
@@ -569,14 +645,14 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     HS_PHASE(NT, if (tid == 0) { double pad[16]; for (int i = 0; i < 16; i++) pad[i] = i < m ? L.lam[i] : 0.0;
                  for (int i = 0; i < ntd; i++) for (int d = 0; d < 3; d++) L.fext[3 * tdfeet[i] + d] = pad[i + d]; })   // WBM.cpp:454: offset i, not 3i
     wb_dpass<NT>(L, D, md, 0.0, 0.0, 0.0, 0.0, true);
-    HS_PHASE(NT, if (tid < 18) for (int i = 0; i < 18; i++) D.W[i * 64 + tid] += D.W[i * 64 + 36 + tid];)
+    HS_PHASE(NT, if (tid < 18) for (int i = 0; i < 18; i++) D.W[i * WT + tid] += D.W[i * WT + 36 + tid];)
     // pass B: d(J v+)/dq with psi_kin: kinematic lanes with the velocity replaced by v+  (pre-impact v kept in xb)
     HS_PHASE(NT, if (tid < 18) { L.xb[tid] = L.x[18 + tid]; })
     HS_PHASE(NT, if (tid < 18) { L.x[18 + tid] = L.qdd[tid]; })
     HS_PHASE(NT, if (tid >= 36 && tid < 54) {
         LaneCfg c = lane_cfg(md, true, 0.0, 0.0, 0.0, 1.0, 0.0, -1, tid - 36, -1);
-        struct VSink { WbDeriv* D; int j; HD void tau(int, const Dual&) const {} HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>&) const {
-            D->dvel[(3 * f) * 18 + j] = v.x.d; D->dvel[(3 * f + 1) * 18 + j] = v.y.d; D->dvel[(3 * f + 2) * 18 + j] = v.z.d; } } sk{&D, tid - 36};
+        struct VSink { WbCore* C; int j; HD void tau(int, const Dual&) const {} HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>&) const {
+            C->dvel()[(3 * f) * 18 + j] = v.x.d; C->dvel()[(3 * f + 1) * 18 + j] = v.y.d; C->dvel()[(3 * f + 2) * 18 + j] = v.z.d; } } sk{&L, tid - 36};
         wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
     })
     // Px = [I 0; dv+/dq dv+/dv] , dv+/dq = -TL*dtau_dq - TR*dv_dq ; dv+/dv = TL*M ; staged in W rows (column d per lane)
@@ -585,18 +661,18 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
         for (int i = 0; i < 18; i++) {
             double s = 0;
             if (d < 18) {
-                for (int j = 0; j < 18; j++) s -= D.Kinv[i * 30 + j] * D.W[j * 64 + d];
-                for (int a = 0; a < m; a++) s -= D.Kinv[i * 30 + 18 + a] * D.dvel[(3 * tdfeet[a / 3] + a % 3) * 18 + d];
+                for (int j = 0; j < 18; j++) s -= D.Kinv[i * 30 + j] * D.W[j * WT + d];
+                for (int a = 0; a < m; a++) s -= D.Kinv[i * 30 + 18 + a] * L.dvel()[(3 * tdfeet[a / 3] + a % 3) * 18 + d];
             } else { for (int j = 0; j < 18; j++) s += D.Kinv[i * 30 + j] * L.M[j * 18 + (d - 18)]; }
             // results into rows 18..35 of W (rows 0..17 still hold the tangents other lanes read)
-            D.W[(18 + i) * 64 + d] = s;
+            D.W[WR0 + i * 36 + d] = s;
         }
     })
     HS_PHASE(NT, for (int e = tid; e < nn * 36; e += NT) {
         const int r = e % nn, c = e / nn;
         double v;
-        if (nn == 36) v = (r < 18) ? ((r == c) ? 1.0 : 0.0) : D.W[r * 64 + c];
-        else v = (r < 6) ? ((r == c) ? 1.0 : 0.0) : D.W[(18 + r - 6) * 64 + c];
+        if (nn == 36) v = (r < 18) ? ((r == c) ? 1.0 : 0.0) : D.W[WR0 + (r - 18) * 36 + c];
+        else v = (r < 6) ? ((r == c) ? 1.0 : 0.0) : D.W[WR0 + (r - 6) * 36 + c];
         P.Px[(size_t)b * nn * 36 + e] = v;
     })
 }

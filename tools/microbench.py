@@ -18,3 +18,14 @@ for _ in range(a.reps):
 kt = s.kernel_times()
 for k, (ms, n) in sorted(kt.items()):
     print(f"{k:18s} {ms / n:10.3f} ms/launch  ({n} launches)")
+import ctypes
+lib = pkg.load_hip_library()
+if hasattr(lib, "hsddp_debug_sweep_prof"):
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.hsddp_debug_sweep_prof(buf, 1)
+    s.backward_sweep(0.0)
+    lib.hsddp_debug_sweep_prof(buf, 0)
+    names = ["load", "HA/HB", "Qxx/Qux/Quu", "reg+store", "store Quu/Qux", "chol+inv", "symm", "K,dU", "H,G", "store K"]
+    tot = sum(buf)
+    for i, n in enumerate(names[:9] if False else names):
+        if i < 16: print(f"  stamp {i} {n:16s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
