@@ -25,6 +25,10 @@
 #define HS_WPHASE(...) { if (threadIdx.x < 64) { const int tid = threadIdx.x; { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
+// compiler-only memory barrier: stops the scheduler from hoisting a whole unrolled recurrence's LDS loads ahead of it
+// (hundreds of live registers); emits no instruction
+#define HS_CBAR() asm volatile("" ::: "memory")
+
 namespace hs {
 
 constexpr int WAVE = 64;

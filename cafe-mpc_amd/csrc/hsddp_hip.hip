@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph, const int* slot
     }
 }
 
-__global__ void __launch_bounds__(SW_NT) k_sweep(const PhaseDev* ph, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
+__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
                                                 int do_linear, double lin_eps, int* success_out) {
     const int b = blockIdx.x;
     if (masked_out(st[b], mask)) return;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(SW_NT) k_sweep(const PhaseDev* ph, int nph, Op
     if (threadIdx.x == 0) { st[b].dV_1 = S.dV1; st[b].dV_2 = S.dV2; }
 }
 
-__global__ void __launch_bounds__(SW_NT) k_linear(const PhaseDev* ph, int nph, ProbState* st, double eps) {
+__global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph, int nph, ProbState* st, double eps) {
     __shared__ SweepLds S;
     linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
     __syncthreads();

@@ -10,28 +10,40 @@
 // accept/reject decision is the same (a non-positive pivot <=> not positive definite), the inverse agrees to rounding.
 // lux is identically zero for every cost the reference ships (SinglePhaseInterface.cpp:47, MHPCCost.cpp) and is not stored.
 //
-// LDS layout: every matrix is column-major with an ODD padded leading dimension (37 for n-row, 13 for m/p-row
-// matrices): with 8-byte elements a stride of 37 (=74 dwords) or 13 (=26 dwords) maps the 3x2 register tiles of a
-// wave onto distinct bank pairs, so the transposed products (A^T HA, B^T HB, C^T lyy C ...) read LDS conflict-free.
-// Each thread owns a 3x2 output tile (6 FMAs per 5 LDS reads).  The 12x12 Cholesky/inverse runs inside ONE wave
-// (wave-level phases, no s_barrier) while the workgroup barrier count per knot stays at ~10.
+// MI355X structure (dims are template constants: whole body 36/12/12):
+//  * LDS: every matrix column-major with an ODD padded leading dimension (37 / 13): the register tiles of a wave then hit
+//    distinct bank pairs also in the transposed products (A^T HA, B^T HB, C^T lyy C ...).
+//  * each thread owns one 3x3 or 3x2 output tile, inner dimension fully unrolled (loads batched ahead of the FMAs).
+//  * the NEXT knot's 32 KB (A, lxx, B, C, D, luu, lyy, vectors) is prefetched from HBM into 20 registers per thread
+//    while the current knot computes, and committed to LDS at the top of the next iteration: HBM latency is off the
+//    sequential critical path.
+//  * the 12x12 Cholesky + inverse runs inside wave 0 with unrolled register recurrences (no workgroup barrier).
 #pragma once
 #include "hs_types.hpp"
 
 namespace hs {
 
 constexpr int SW_NT = 256;
-constexpr int SW_M = 12;    // control dimension bound of this build (whole-body phases); HKD (m=24) needs its own instantiation
+constexpr int SW_N = 36, SW_M = 12, SW_P = 12;   // dimension bound of this build (whole-body phases)
 constexpr int LDN = 37;     // padded leading dimension of n-row matrices
 constexpr int LDM = 13;     // padded leading dimension of m-row / p-row matrices
+constexpr int SW_PRE = 20;  // prefetch registers per thread
+#ifndef SW_UNROLL_N
+#define SW_UNROLL_N 4
+#endif
+#define HS_STR_(x) #x
+#define HS_UNROLL_N(n) _Pragma(HS_STR_(unroll n))
+#ifndef SW_MINB
+#define SW_MINB 2
+#endif
 
 struct SweepLds {
-    double H[LDN * MAXN], A[LDN * MAXN], HA[LDN * MAXN], Qxx[LDN * MAXN];
+    double H[LDN * SW_N], A[LDN * SW_N], HA[LDN * SW_N], Qxx[LDN * SW_N];
     double B[LDN * SW_M], HB[LDN * SW_M];
-    double Qux[LDM * MAXN], K[LDM * MAXN], C[LDM * MAXN], lC[LDM * MAXN];
-    double D[LDM * SW_M], lD[LDM * SW_M], lyy[LDM * MAXP], Quu[LDM * SW_M], LQ[LDM * SW_M], Qi[LDM * SW_M];
-    double G[MAXN], Gn[MAXN], Qx[MAXN], Qu[SW_M], dU[SW_M], ly[MAXP], def[MAXN], tmp[64];
-    double dx[MAXN], dxn[MAXN], du[SW_M];
+    double Qux[LDM * SW_N], K[LDM * SW_N], C[LDM * SW_N], lC[LDM * SW_N];
+    double D[LDM * SW_M], lD[LDM * SW_M], lyy[LDM * SW_P], Quu[LDM * SW_M], LQ[LDM * SW_M], Qi[LDM * SW_M];
+    double G[SW_N], Gn[SW_N], Qx[SW_N], Qu[SW_M], dU[SW_M], ly[SW_P], def[SW_N], rdQ[SW_M];
+    double dx[SW_N], dxn[SW_N], du[SW_M];
     double red[SW_NT];
     double dV1, dV2;
     unsigned long long t_last;
@@ -50,25 +62,81 @@ __device__ unsigned long long g_sw_prof[16];
 #define SW_STAMP0()
 #endif
 
-// One 3x2 register tile of  C(i,j) (+)= alpha * sum_t opA(i,t) * B(t,j) ;  opA(i,t) = TA ? A[t + lda*i] : A[i + lda*t]
-template <bool TA>
-HD void mm_tile(int tile, double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int K, bool acc, double alpha) {
-    const int nti = M / 3, ti = tile % nti, tj = tile / nti, i0 = 3 * ti, j0 = 2 * tj;
-    double c00 = 0, c10 = 0, c20 = 0, c01 = 0, c11 = 0, c21 = 0;
-    for (int t = 0; t < K; t++) {
-        double a0, a1, a2;
-        if (TA) { a0 = A[t + lda * i0]; a1 = A[t + lda * (i0 + 1)]; a2 = A[t + lda * (i0 + 2)]; }
-        else { a0 = A[i0 + lda * t]; a1 = A[i0 + 1 + lda * t]; a2 = A[i0 + 2 + lda * t]; }
-        const double b0 = B[t + ldb * j0], b1 = B[t + ldb * (j0 + 1)];
-        c00 += a0 * b0; c10 += a1 * b0; c20 += a2 * b0; c01 += a0 * b1; c11 += a1 * b1; c21 += a2 * b1;
-    }
-    double* c0 = C + i0 + ldc * j0; double* c1 = c0 + ldc;
-    if (acc) { c0[0] += alpha * c00; c0[1] += alpha * c10; c0[2] += alpha * c20; c1[0] += alpha * c01; c1[1] += alpha * c11; c1[2] += alpha * c21; }
-    else { c0[0] = alpha * c00; c0[1] = alpha * c10; c0[2] = alpha * c20; c1[0] = alpha * c01; c1[1] = alpha * c11; c1[2] = alpha * c21; }
-}
-HD int ntiles(int M, int N) { return (M / 3) * (N / 2); }
+// per-thread prefetch registers (the host lane emulator keeps one row per emulated thread)
+#ifdef HS_HOST_EMU
+#define SW_PRE_DECL static double pre_all_[SW_NT][SW_PRE];
+#define PRE(r) pre_all_[tid][r]
+#else
+#define SW_PRE_DECL double pre_[SW_PRE];
+#define PRE(r) pre_[r]
+#endif
 
-// global (dense, ld = rows) -> LDS (padded ld); threads stride over columns with a fixed row
+// One TI x TJ register tile of  C(i,j) (+)= alpha * sum_t opA(i,t) * B(t,j) ;  opA(i,t) = TA ? A[t + lda*i] : A[i + lda*t]
+template <bool TA, int TI, int TJ, int K>
+HD void mm_tile(int tile, int nti, double* C, int ldc, const double* A, int lda, const double* B, int ldb, bool acc, double alpha) {
+    const int ti = tile % nti, tj = tile / nti, i0 = TI * ti, j0 = TJ * tj;
+    double c[TI][TJ];
+    _Pragma("unroll")
+    for (int ii = 0; ii < TI; ii++) { _Pragma("unroll") for (int jj = 0; jj < TJ; jj++) c[ii][jj] = 0.0; }
+    HS_UNROLL_N(SW_UNROLL_N)    // loads in flight per tile vs registers (full unrolling needs ~450 registers -> 1 block per CU)
+    for (int t = 0; t < K; t++) {
+        double a[TI], bb[TJ];
+        _Pragma("unroll")
+        for (int ii = 0; ii < TI; ii++) a[ii] = TA ? A[t + lda * (i0 + ii)] : A[i0 + ii + lda * t];
+        _Pragma("unroll")
+        for (int jj = 0; jj < TJ; jj++) bb[jj] = B[t + ldb * (j0 + jj)];
+        _Pragma("unroll")
+        for (int ii = 0; ii < TI; ii++) { _Pragma("unroll") for (int jj = 0; jj < TJ; jj++) c[ii][jj] += a[ii] * bb[jj]; }
+    }
+    _Pragma("unroll")
+    for (int jj = 0; jj < TJ; jj++) {
+        _Pragma("unroll")
+        for (int ii = 0; ii < TI; ii++) {
+            double* p = C + (i0 + ii) + ldc * (j0 + jj);
+            *p = acc ? (*p + alpha * c[ii][jj]) : alpha * c[ii][jj];
+        }
+    }
+}
+
+// ---- wave-level (wave 0) factorisation helpers, compile-time size, recurrences in registers -------------------
+template <int N, int LD>
+HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok) {
+    _Pragma("unroll")
+    for (int j = 0; j < N; j++) {
+        HS_WPHASE(if (tid >= j && tid < N) {
+            double sj = CM(A, j, j, LD) + diag_add, st = CM(A, tid, j, LD);
+            _Pragma("unroll")
+            for (int k = 0; k < j; k++) { const double ljk = Lo[j * LD + k]; sj -= ljk * ljk; st -= Lo[tid * LD + k] * ljk; }
+            const bool good = sj > 0.0;
+            const double d = sqrt(good ? sj : 1.0);
+            if (tid == j) { rd[j] = 1.0 / d; if (!good) *ok = 0; } else Lo[tid * LD + j] = st / d;
+        })
+    }
+}
+template <int N, int LD>
+HD void inv_col_w(const double* Lo, const double* rd, double* Inv, int c) {   // Inv[i*LD + c], symmetric
+    double y[N];
+    _Pragma("unroll")
+    for (int i = 0; i < N; i++) {
+        double s = (i == c) ? 1.0 : 0.0;
+        _Pragma("unroll")
+        for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * y[k];
+        y[i] = s * rd[i];
+        HS_CBAR();
+    }
+    _Pragma("unroll")
+    for (int i = N - 1; i >= 0; i--) {
+        double s = y[i];
+        _Pragma("unroll")
+        for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * y[k];
+        y[i] = s * rd[i];
+        HS_CBAR();
+    }
+    _Pragma("unroll")
+    for (int i = 0; i < N; i++) Inv[i * LD + c] = y[i];
+}
+
+// global (dense, ld = rows) <-> LDS (padded ld); threads stride over columns with a fixed row
 template <int NT> HD void ld_mat(int tid, double* dst, int ldd, const double* src, int rows, int cols) {
     const int i = tid % rows, j0 = tid / rows, js = NT / rows;
     if (j0 < js) for (int j = j0; j < cols; j += js) dst[i + ldd * j] = src[i + rows * j];
@@ -78,194 +146,196 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     if (j0 < js) for (int j = j0; j < cols; j += js) dst[i + rows * j] = src[i + lds_ * j];
 }
 
+// ---- prefetch of one knot's record (backward sweep): 20 rounds of 256 elements, each round inside ONE array ----
+//   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 C | 16 D | 17 luu | 18 lyy | 19 [lx(36) lu(12) ly(12) Defect[k+1](36)]
+#define SW_RICCATI_FETCH(kk_, k_) { \
+    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; PRE(r) = (e < N * N) ? P.A[(kk_) * N * N + e] : 0.0; PRE(6 + r) = (e < N * N) ? P.lxx[(kk_) * N * N + e] : 0.0; } \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = (e < N * M) ? P.B[(kk_) * N * M + e] : 0.0; PRE(14 + r) = (e < PY * N) ? P.C[(kk_) * PY * N + e] : 0.0; } \
+    PRE(16) = (tid < PY * M) ? P.D[(kk_) * PY * M + tid] : 0.0; PRE(17) = (tid < M * M) ? P.luu[(kk_) * M * M + tid] : 0.0; PRE(18) = (tid < PY * PY) ? P.lyy[(kk_) * PY * PY + tid] : 0.0; \
+    PRE(19) = (tid < N) ? P.lx[(kk_) * N + tid] : (tid < N + M) ? P.lu[(kk_) * M + tid - N] : (tid < N + M + PY) ? P.ly[(kk_) * PY + tid - N - M] \
+            : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
+#define SW_RICCATI_COMMIT() { \
+    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(6 + r); } } \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; if (e < N * M) S.B[(e % N) + LDN * (e / N)] = PRE(12 + r); if (e < PY * N) S.C[(e % PY) + LDM * (e / PY)] = PRE(14 + r); } \
+    if (tid < PY * M) S.D[(tid % PY) + LDM * (tid / PY)] = PRE(16); if (tid < M * M) S.Quu[(tid % M) + LDM * (tid / M)] = PRE(17); if (tid < PY * PY) S.lyy[(tid % PY) + LDM * (tid / PY)] = PRE(18); \
+    if (tid < N) S.Qx[tid] = PRE(19); else if (tid < N + M) S.Qu[tid - N] = PRE(19); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(19); else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(19); }
+
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
-template <int NT>
+template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
-    const int n = P.n, m = P.m, p = P.p, h = P.h;
-    // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327)
-    HS_PHASE(NT, { const int i = tid % n, j0 = tid / n, js = NT / n; if (j0 < js) for (int j = j0; j < n; j += js) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * n * n + i + n * j]; }
-             if (tid < n) { S.G[tid] += P.Phix[(size_t)b * n + tid]; P.G[((size_t)b * (h + 1) + h) * n + tid] = S.G[tid]; }
-             if (tid == 0) { S.ok = 1; })
+    static_assert(NT == 256 && N % 3 == 0 && M % 3 == 0 && PY % 3 == 0 && N % 2 == 0 && M % 2 == 0, "tile shapes");
+    const int h = P.h;
+    SW_PRE_DECL
+    // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327); prefetch knot h-1
+    HS_PHASE(NT, { const int i = tid % N, j0 = tid / N; if (j0 < NT / N) for (int j = j0; j < N; j += NT / N) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * N * N + i + N * j]; }
+             if (tid < N) { S.G[tid] += P.Phix[(size_t)b * N + tid]; P.G[((size_t)b * (h + 1) + h) * N + tid] = S.G[tid]; }
+             if (tid == 0) { S.ok = 1; }
+             SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1))
     for (int k = h - 1; k >= 0; k--) {
         const size_t kk = (size_t)b * h + k;
         SW_STAMP0()
-        HS_PHASE(NT,
-            ld_mat<NT>(tid, S.A, LDN, P.A + kk * n * n, n, n); ld_mat<NT>(tid, S.Qxx, LDN, P.lxx + kk * n * n, n, n);
-            ld_mat<NT>(tid, S.B, LDN, P.B + kk * n * m, n, m); ld_mat<NT>(tid, S.Quu, LDM, P.luu + kk * m * m, m, m);
-            if (p > 0) {
-                ld_mat<NT>(tid, S.C, LDM, P.C + kk * p * n, p, n); ld_mat<NT>(tid, S.D, LDM, P.D + kk * p * m, p, m);
-                ld_mat<NT>(tid, S.lyy, LDM, P.lyy + kk * p * p, p, p);
-                if (tid < p) S.ly[tid] = P.ly[kk * p + tid];
-            }
-            if (tid < n) { S.Qx[tid] = P.lx[kk * n + tid]; S.def[tid] = P.Defect[((size_t)b * (h + 1) + k + 1) * n + tid]; }
-            if (tid < m) S.Qu[tid] = P.lu[kk * m + tid];)
+        HS_PHASE(NT, SW_RICCATI_COMMIT() if (k > 0) SW_RICCATI_FETCH(kk - 1, k - 1))
         SW_STAMP(0)
-        // HA = H A ; HB = H B ; Gnext = G + H Defect[k+1] ; (p>0) lC = lyy C ; lD = lyy D
+        // HA = H A (3x3 tiles) ; HB = H B ; lC = lyy C ; lD = lyy D (3x2 tiles) ; Gnext = G + H Defect[k+1]
         {
-            const int t1 = ntiles(n, n), t2 = t1 + ntiles(n, m), t3 = t2 + (p > 0 ? ntiles(p, n) : 0), t4 = t3 + (p > 0 ? ntiles(p, m) : 0);
+            constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (N / 3) * (M / 2), t3 = t2 + (PY > 0 ? (PY / 3) * (N / 2) : 0), t4 = t3 + (PY > 0 ? (PY / 3) * (M / 2) : 0);
             HS_PHASE(NT,
                 for (int tile = tid; tile < t4; tile += NT) {
-                    if (tile < t1) mm_tile<false>(tile, S.HA, LDN, S.H, LDN, S.A, LDN, n, n, false, 1.0);
-                    else if (tile < t2) mm_tile<false>(tile - t1, S.HB, LDN, S.H, LDN, S.B, LDN, n, n, false, 1.0);
-                    else if (tile < t3) mm_tile<false>(tile - t2, S.lC, LDM, S.lyy, LDM, S.C, LDM, p, p, false, 1.0);
-                    else mm_tile<false>(tile - t3, S.lD, LDM, S.lyy, LDM, S.D, LDM, p, p, false, 1.0);
+                    if (tile < t1) mm_tile<false, 3, 3, N>(tile, N / 3, S.HA, LDN, S.H, LDN, S.A, LDN, false, 1.0);
+                    else if (tile < t2) mm_tile<false, 3, 2, N>(tile - t1, N / 3, S.HB, LDN, S.H, LDN, S.B, LDN, false, 1.0);
+                    else if (tile < t3) mm_tile<false, 3, 2, (PY > 0 ? PY : 1)>(tile - t2, PY / 3, S.lC, LDM, S.lyy, LDM, S.C, LDM, false, 1.0);
+                    else mm_tile<false, 3, 2, (PY > 0 ? PY : 1)>(tile - t3, PY / 3, S.lD, LDM, S.lyy, LDM, S.D, LDM, false, 1.0);
                 }
-                if (tid >= NT - n) { const int i = tid - (NT - n); double s = S.G[i]; for (int j = 0; j < n; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; })
+                if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.G[i]; _Pragma("unroll") for (int j = 0; j < N; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; })
         }
         SW_STAMP(1)
         // Qxx += A^T HA (+ C^T lC) ; Qux = B^T HA (+ D^T lC) ; Quu += B^T HB (+ D^T lD) ; Qx += A^T Gn (+C^T ly) ; Qu += B^T Gn (+D^T ly)
         {
-            const int t1 = ntiles(n, n), t2 = t1 + ntiles(m, n), t3 = t2 + ntiles(m, m);
+            constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (M / 3) * (N / 2);
             HS_PHASE(NT,
-                for (int tile = tid; tile < t3; tile += NT) {
-                    if (tile < t1) { mm_tile<true>(tile, S.Qxx, LDN, S.A, LDN, S.HA, LDN, n, n, true, 1.0); if (p > 0) mm_tile<true>(tile, S.Qxx, LDN, S.C, LDM, S.lC, LDM, n, p, true, 1.0); }
-                    else if (tile < t2) { mm_tile<true>(tile - t1, S.Qux, LDM, S.B, LDN, S.HA, LDN, m, n, false, 1.0); if (p > 0) mm_tile<true>(tile - t1, S.Qux, LDM, S.D, LDM, S.lC, LDM, m, p, true, 1.0); }
-                    else { mm_tile<true>(tile - t2, S.Quu, LDM, S.B, LDN, S.HB, LDN, m, n, true, 1.0); if (p > 0) mm_tile<true>(tile - t2, S.Quu, LDM, S.D, LDM, S.lD, LDM, m, p, true, 1.0); }
-                }
-                if (tid >= NT - n) {
-                    const int i = tid - (NT - n); double s = 0; for (int t = 0; t < n; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
-                    if (p > 0) for (int t = 0; t < p; t++) s += CM(S.C, t, i, LDM) * S.ly[t];
+                if (tid < t1) { mm_tile<true, 3, 3, N>(tid, N / 3, S.Qxx, LDN, S.A, LDN, S.HA, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 3, (PY > 0 ? PY : 1)>(tid, N / 3, S.Qxx, LDN, S.C, LDM, S.lC, LDM, true, 1.0); }
+                else if (tid < t2) { mm_tile<true, 3, 2, N>(tid - t1, M / 3, S.Qux, LDM, S.B, LDN, S.HA, LDN, false, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid - t1, M / 3, S.Qux, LDM, S.D, LDM, S.lC, LDM, true, 1.0); }
+                else if (tid < t2 + N) {
+                    const int i = tid - t2; double s = 0;
+                    _Pragma("unroll") for (int t = 0; t < N; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
+                    if (PY > 0) { _Pragma("unroll") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
                     S.Qx[i] += s;
-                } else if (tid >= NT - n - m) {
-                    const int a = tid - (NT - n - m); double s = 0; for (int t = 0; t < n; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
-                    if (p > 0) for (int t = 0; t < p; t++) s += CM(S.D, t, a, LDM) * S.ly[t];
-                    S.Qu[a] += s;
                 })
+            constexpr int u1 = (M / 3) * (M / 2);
+            HS_PHASE(NT,
+                if (tid < u1) { mm_tile<true, 3, 2, N>(tid, M / 3, S.Quu, LDM, S.B, LDN, S.HB, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid, M / 3, S.Quu, LDM, S.D, LDM, S.lD, LDM, true, 1.0); }
+                else if (tid >= 64 && tid < 64 + M) {
+                    const int a = tid - 64; double s = 0;
+                    _Pragma("unroll") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
+                    if (PY > 0) { _Pragma("unroll") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
+                    S.Qu[a] += s;
+                } else if (tid >= 128 && tid < 128 + N) CM(S.Qxx, tid - 128, tid - 128, LDN) += reg;)     // regularisation on Qxx: quirk x
         }
         SW_STAMP(2)
-        // regularisation (also on Qxx: quirk x); store Qu / Quu / Qux as the reference keeps them (callers read them)
-        HS_PHASE(NT,
-            if (tid < n) CM(S.Qxx, tid, tid, LDN) += reg;
-            if (tid >= 64 && tid < 64 + m) { const int a = tid - 64; CM(S.Quu, a, a, LDM) += reg; P.Qu[kk * m + a] = S.Qu[a]; })
-        HS_PHASE(NT,
-            st_mat<NT>(tid, P.Quu + kk * m * m, S.Quu, LDM, m, m); st_mat<NT>(tid, P.Qux + kk * m * n, S.Qux, LDM, m, n);
-            )
+        // regularisation on Quu; store Qu / Quu / Qux as the reference keeps them (callers read them)
+        HS_PHASE(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; })
+        HS_PHASE(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
-        // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse, all inside one wave (no workgroup barrier)
-        for (int j = 0; j < m; j++) {
-            HS_WPHASE(if (tid >= j && tid < m) {
-                double s = CM(S.Quu, tid, j, LDM) - ((tid == j) ? 1e-9 : 0.0);
-                for (int t = 0; t < j; t++) s -= S.LQ[tid * LDM + t] * S.LQ[j * LDM + t];
-                S.tmp[tid] = s;
-            })
-            HS_WPHASE(if (tid >= j && tid < m) {
-                const double piv = S.tmp[j];
-                if (tid == j && !(piv > 0.0)) S.ok = 0;
-                const double d = sqrt(piv > 0.0 ? piv : 1.0);
-                S.LQ[tid * LDM + j] = (tid == j) ? d : S.tmp[tid] / d;
-            })
-        }
-        HS_WPHASE(if (tid < m) {   // Quu_inv column tid (symmetric; stored [row*LDM + col])
-            const int c = tid;
-            for (int i = 0; i < m; i++) { double s = (i == c) ? 1.0 : 0.0; for (int t = 0; t < i; t++) s -= S.LQ[i * LDM + t] * S.Qi[t * LDM + c]; S.Qi[i * LDM + c] = s / S.LQ[i * LDM + i]; }
-            for (int i = m - 1; i >= 0; i--) { double s = S.Qi[i * LDM + c]; for (int t = i + 1; t < m; t++) s -= S.LQ[t * LDM + i] * S.Qi[t * LDM + c]; S.Qi[i * LDM + c] = s / S.LQ[i * LDM + i]; }
-        })
+        // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
+        chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &S.ok);
+        HS_WPHASE(if (tid < M) inv_col_w<M, LDM>(S.LQ, S.rdQ, S.Qi, tid);)
         SW_STAMP(4)
-        // symmetrise Qxx (threads >= 64, wave 0 was busy) — pairs (i<j)
         HS_PHASE(NT,
-            for (int e = tid; e < n * n; e += NT) { const int i = e % n, j = e / n; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
+            if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) { const int i = e % N, j = e / N; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
         SW_STAMP(5)
         if (!S.ok) return false;
         // K = -Qi Qux ; dU = -Qi Qu
         HS_PHASE(NT,
-            for (int tile = tid; tile < ntiles(m, n); tile += NT) mm_tile<false>(tile, S.K, LDM, S.Qi, LDM, S.Qux, LDM, m, m, false, -1.0);
-            if (tid >= NT - m) { const int a = tid - (NT - m); double s = 0; for (int t = 0; t < m; t++) s += S.Qi[a * LDM + t] * S.Qu[t]; S.dU[a] = -s; })
+            if (tid < (M / 3) * (N / 2)) mm_tile<false, 3, 2, M>(tid, M / 3, S.K, LDM, S.Qi, LDM, S.Qux, LDM, false, -1.0);
+            else if (tid >= NT - M) { const int a = tid - (NT - M); double s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += S.Qi[a * LDM + t] * S.Qu[t]; S.dU[a] = -s; })
         SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE(NT,
-            for (int tile = tid; tile < ntiles(n, n); tile += NT) {
-                const int nti = n / 3, ti = tile % nti, tj = tile / nti, i0 = 3 * ti, j0 = 2 * tj;
-                for (int jj = 0; jj < 2; jj++) for (int ii = 0; ii < 3; ii++) CM(S.H, i0 + ii, j0 + jj, LDN) = CM(S.Qxx, i0 + ii, j0 + jj, LDN);
-                mm_tile<true>(tile, S.H, LDN, S.Qux, LDM, S.K, LDM, n, m, true, 1.0);
-            }
-            if (tid >= NT - n) { const int i = tid - (NT - n); double s = S.Qx[i]; for (int t = 0; t < m; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * n + i] = s; }
-            else if (tid == NT - n - 1) { double dVk = 0; for (int t = 0; t < m; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
-            else if (tid >= NT - n - 1 - m && tid < NT - n - 1) { const int a = tid - (NT - n - 1 - m); P.dU[kk * m + a] = S.dU[a]; })
+            if (tid < (N / 3) * (N / 3)) {
+                const int ti = tid % (N / 3), tj = tid / (N / 3);
+                _Pragma("unroll") for (int jj = 0; jj < 3; jj++) { _Pragma("unroll") for (int ii = 0; ii < 3; ii++) CM(S.H, 3 * ti + ii, 3 * tj + jj, LDN) = CM(S.Qxx, 3 * ti + ii, 3 * tj + jj, LDN); }
+                mm_tile<true, 3, 3, M>(tid, N / 3, S.H, LDN, S.Qux, LDM, S.K, LDM, true, 1.0);
+            } else if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
+            else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
+            else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
-        HS_PHASE(NT, st_mat<NT>(tid, P.K + kk * m * n, S.K, LDM, m, n);)
+        HS_PHASE(NT, st_mat<NT>(tid, P.K + kk * M * N, S.K, LDM, M, N);)
         SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
-    HS_PHASE(NT, if (tid < n) S.def[tid] = P.Defect[((size_t)b * (h + 1)) * n + tid];)
-    HS_PHASE(NT, if (tid < n) { double s = S.G[tid]; for (int j = 0; j < n; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
-    HS_PHASE(NT, if (tid < n) { S.G[tid] = S.Gn[tid]; P.G[((size_t)b * (h + 1)) * n + tid] = S.Gn[tid]; }
-             st_mat<NT>(tid, P.H0 + (size_t)b * n * n, S.H, LDN, n, n);)
+    HS_PHASE(NT, if (tid < N) S.def[tid] = P.Defect[((size_t)b * (h + 1)) * N + tid];)
+    HS_PHASE(NT, if (tid < N) { double s = S.G[tid]; for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
+    HS_PHASE(NT, if (tid < N) { S.G[tid] = S.Gn[tid]; P.G[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
+             st_mat<NT>(tid, P.H0 + (size_t)b * N * N, S.H, LDN, N, N);)
     return true;
 }
 
-// full multi-phase backward sweep of problem b; returns success, writes dV into S.dV1/dV2
-template <int NT>
-HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
+// full multi-phase backward sweep of problem b; returns success, writes dV into S.dV1/dV2.  All phases N/M/PY.
+template <int NT, int N, int M, int PY>
+HD bool riccati_sweep_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
     HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
         const PhaseDev& P = ph[i];
-        const int n = P.n;
         if (i == nph - 1) {
-            HS_PHASE(NT, for (int e = tid; e < LDN * n; e += NT) S.H[e] = 0.0; if (tid < n) S.G[tid] = 0.0;)
-        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = next_n x n  (MultiPhaseDDP.cpp:196-201)
-            const int nn = P.next_n;
-            HS_PHASE(NT, ld_mat<NT>(tid, S.A, LDN, P.Px + (size_t)b * nn * n, nn, n);)
+            HS_PHASE(NT, for (int e = tid; e < LDN * N; e += NT) S.H[e] = 0.0; if (tid < N) S.G[tid] = 0.0;)
+        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = N x N here  (MultiPhaseDDP.cpp:196-201)
+            HS_PHASE(NT, ld_mat<NT>(tid, S.A, LDN, P.Px + (size_t)b * N * N, N, N);)
             HS_PHASE(NT,
-                for (int tile = tid; tile < ntiles(nn, n); tile += NT) mm_tile<false>(tile, S.HA, LDN, S.H, LDN, S.A, LDN, nn, nn, false, 1.0);
-                if (tid >= NT - n) { const int i2 = tid - (NT - n); double s = 0; for (int t = 0; t < nn; t++) s += CM(S.A, t, i2, LDN) * S.G[t]; S.Gn[i2] = s; })
+                if (tid < (N / 3) * (N / 3)) mm_tile<false, 3, 3, N>(tid, N / 3, S.HA, LDN, S.H, LDN, S.A, LDN, false, 1.0);
+                else if (tid >= NT - N) { const int i2 = tid - (NT - N); double s = 0; for (int t = 0; t < N; t++) s += CM(S.A, t, i2, LDN) * S.G[t]; S.Gn[i2] = s; })
             HS_PHASE(NT,
-                for (int tile = tid; tile < ntiles(n, n); tile += NT) mm_tile<true>(tile, S.H, LDN, S.A, LDN, S.HA, LDN, n, nn, false, 1.0);
-                if (tid >= NT - n) S.G[tid - (NT - n)] = S.Gn[tid - (NT - n)];)
+                if (tid < (N / 3) * (N / 3)) mm_tile<true, 3, 3, N>(tid, N / 3, S.H, LDN, S.A, LDN, S.HA, LDN, false, 1.0);
+                else if (tid >= NT - N) S.G[tid - (NT - N)] = S.Gn[tid - (NT - N)];)
         }
-        if (!riccati_phase<NT>(S, P, b, reg)) return false;
+        if (!riccati_phase<NT, N, M, PY>(S, P, b, reg)) return false;
     }
     return true;
 }
-
-// linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.dV1/dV2.  (dense ld = rows layouts here:
-// the matvecs read rows with unit stride across threads)
 template <int NT>
-HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
-    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; } if (tid < MAXN) S.dxn[tid] = 0.0;)
+HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) { return riccati_sweep_t<NT, SW_N, SW_M, SW_P>(S, ph, nph, b, reg); }
+
+// ---- linear rollout: forward over phases/knots; next knot prefetched into 18 registers per thread (dense ld = rows) ----
+//   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 K | 16 luu | 17 [lx(36) lu(12) dU(12) Defect[k+1](36)]
+#define SW_LIN_FETCH(kk_, k_) { \
+    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; PRE(r) = (e < N * N) ? P.A[(kk_) * N * N + e] : 0.0; PRE(6 + r) = (e < N * N) ? P.lxx[(kk_) * N * N + e] : 0.0; } \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = (e < N * M) ? P.B[(kk_) * N * M + e] : 0.0; PRE(14 + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
+    PRE(16) = (tid < M * M) ? P.luu[(kk_) * M * M + tid] : 0.0; \
+    PRE(17) = (tid < N) ? P.lx[(kk_) * N + tid] : (tid < N + M) ? P.lu[(kk_) * M + tid - N] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
+            : (tid < 2 * N + 2 * M) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
+#define SW_LIN_COMMIT() { \
+    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[e] = PRE(r); S.Qxx[e] = PRE(6 + r); } } \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; if (e < N * M) { S.B[e] = PRE(12 + r); S.K[e] = PRE(14 + r); } } \
+    if (tid < M * M) S.Quu[tid] = PRE(16); \
+    if (tid < N) S.Qx[tid] = PRE(17); else if (tid < N + M) S.Qu[tid - N] = PRE(17); else if (tid < N + 2 * M) S.dU[tid - N - M] = PRE(17); else if (tid < 2 * N + 2 * M) S.def[tid - N - 2 * M] = PRE(17); }
+
+template <int NT, int N, int M>
+HD void linear_rollout_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
+    SW_PRE_DECL
+    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; } if (tid < N) S.dxn[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
         const PhaseDev& P = ph[i];
-        const int n = P.n, m = P.m, h = P.h;
+        const int h = P.h;
         if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); S.dx holds prev terminal dX
-            const PhaseDev& Pp = ph[i - 1]; const int np = Pp.n;
-            HS_PHASE(NT, for (int e = tid; e < n * np; e += NT) S.A[e] = Pp.Px[(size_t)b * n * np + e];)
-            HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += CM(S.A, tid, t, n) * S.dx[t]; S.dxn[tid] = s; })
+            const PhaseDev& Pp = ph[i - 1];
+            HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.A[e] = Pp.Px[(size_t)b * N * N + e];)
+            HS_PHASE(NT, if (tid < N) { double s = 0; for (int t = 0; t < N; t++) s += CM(S.A, tid, t, N) * S.dx[t]; S.dxn[tid] = s; })
         }
         // dX[0] = dx_init + eps * Defect[0]
-        HS_PHASE(NT, if (tid < n) { double v = S.dxn[tid] + eps * P.Defect[((size_t)b * (h + 1)) * n + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * n + tid] = v; })
+        HS_PHASE(NT, if (tid < N) { double v = S.dxn[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
+                 SW_LIN_FETCH((size_t)b * h, 0))
         for (int k = 0; k < h; k++) {
             const size_t kk = (size_t)b * h + k;
+            HS_PHASE(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
+            HS_PHASE(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
             HS_PHASE(NT,
-                for (int e = tid; e < n * n; e += NT) { S.A[e] = P.A[kk * n * n + e]; S.Qxx[e] = P.lxx[kk * n * n + e]; }
-                for (int e = tid; e < n * m; e += NT) { S.B[e] = P.B[kk * n * m + e]; S.K[e] = P.K[kk * m * n + e]; }
-                for (int e = tid; e < m * m; e += NT) S.Quu[e] = P.luu[kk * m * m + e];
-                if (tid < n) { S.Qx[tid] = P.lx[kk * n + tid]; S.def[tid] = P.Defect[((size_t)b * (h + 1) + k + 1) * n + tid]; }
-                if (tid < m) { S.Qu[tid] = P.lu[kk * m + tid]; S.dU[tid] = P.dU[kk * m + tid]; })
-            HS_PHASE(NT, if (tid < m) { double s = eps * S.dU[tid]; for (int j = 0; j < n; j++) s += CM(S.K, tid, j, m) * S.dx[j]; S.du[tid] = s; })
-            HS_PHASE(NT,
-                if (tid < n) {
-                    double s = 0; for (int j = 0; j < n; j++) s += CM(S.A, tid, j, n) * S.dx[j];
-                    double s2 = 0; for (int j = 0; j < m; j++) s2 += CM(S.B, tid, j, n) * S.du[j];
-                    double v = s + s2 + eps * S.def[tid];
-                    S.dxn[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * n + tid] = v;
-                    double q = 0; for (int j = 0; j < n; j++) q += CM(S.Qxx, tid, j, n) * S.dx[j];
+                if (tid < N) {
+                    double s = 0, q = 0;
+                    _Pragma("unroll") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
+                    double s2 = 0;
+                    _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(S.B, tid, j, N) * S.du[j];
+                    const double v = s + s2 + eps * S.def[tid];
+                    S.dxn[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
                     S.red[tid] = S.dx[tid] * q;            // dx^T lxx dx contributions
                     S.red[64 + tid] = S.Qx[tid] * S.dx[tid];
-                } else if (tid >= 128 && tid < 128 + m) {
-                    int a = tid - 128; double q = 0; for (int j = 0; j < m; j++) q += CM(S.Quu, a, j, m) * S.du[j];
+                } else if (tid >= 128 && tid < 128 + M) {
+                    const int a = tid - 128; double q = 0;
+                    _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(S.Quu, a, j, M) * S.du[j];
                     S.red[tid] = S.du[a] * q; S.red[64 + tid] = S.Qu[a] * S.du[a];
                 })
             HS_PHASE(NT, if (tid == 0) {
                 double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
-                for (int j = 0; j < n; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
-                for (int j = 0; j < m; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
+                for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
+                for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
                 S.dV1 += a1 + b1; S.dV2 += a2; S.dV2 += b2;      // (+ du^T lux dx with lux == 0)
-            } if (tid < n) S.dx[tid] = S.dxn[tid];)
+            } if (tid >= 64 && tid < 64 + N) S.dx[tid - 64] = S.dxn[tid - 64];)
         }
         // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx
-        HS_PHASE(NT, for (int e = tid; e < n * n; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * n * n + e];)
-        HS_PHASE(NT, if (tid < n) { double q = 0; for (int j = 0; j < n; j++) q += CM(S.Qxx, tid, j, n) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * n + tid] * S.dx[tid]; })
-        HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < n; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } S.dV1 += a1; S.dV2 += a2; })
+        HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
+        HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * N + tid] * S.dx[tid]; })
+        HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } S.dV1 += a1; S.dV2 += a2; })
     }
 }
+template <int NT>
+HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) { linear_rollout_t<NT, SW_N, SW_M>(S, ph, nph, b, eps); }
 
 }  // namespace hs

@@ -81,6 +81,7 @@ template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, doubl
         _Pragma("unroll")
         for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * x[k];
         x[i] = s * rd[i];
+        HS_CBAR();
     }
 }
 // x = L^-T b (backward) in registers
@@ -91,6 +92,7 @@ template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, doubl
         _Pragma("unroll")
         for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * x[k];
         x[i] = s * rd[i];
+        HS_CBAR();
     }
 }
 // column c of (L L^T)^-1 into Inv[:, c] (row-major ldi). Called by lane c.
@@ -172,6 +174,7 @@ HD void wb_gram(WbCore& L, int m, int tid, double rhs_dot) {
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.Xm()[i * 12 + tid];
         L.G()[a * 12 + tid] = (tid >= m || a >= m) ? ((a == tid) ? 1.0 : 0.0) : s;
+        HS_CBAR();
     }
     L.rhs[tid] = (tid < m) ? (-rhs_dot - L.gam[tid]) : 0.0;
 }
