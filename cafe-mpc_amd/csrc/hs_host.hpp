@@ -54,13 +54,16 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     auto al = [&](double** dst, size_t cnt) { void* p = mem.alloc(std::max<size_t>(cnt, 1) * 8); if (!p) ok = false; *dst = (double*)p; };
     double** sx[] = {&P.X, &P.Xbar, &P.Xsim, &P.Defect, &P.Defect_bar, &P.dX, &P.G};
     for (auto p : sx) al(p, B * h1 * 36);
-    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu, &P.Y, &P.lu, &P.ly};
+    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu, &P.Y};
     for (auto p : su) al(p, B * hh * 12);
-    double** s432[] = {&P.K, &P.Qux, &P.B, &P.C};
+    double** s432[] = {&P.K, &P.Qux};
     for (auto p : s432) al(p, B * hh * 432);
-    double** s144[] = {&P.Quu, &P.D, &P.luu, &P.lyy};
+    double** s144[] = {&P.Quu};
     for (auto p : s144) al(p, B * hh * 144);
-    al(&P.A, B * hh * 1296); al(&P.lxx, B * hh * 1296); al(&P.lx, B * hh * 36); al(&P.l, B * hh); al(&P.lbase, B * hh);
+    P.rs = REC_SIZE; al(&P.rec, B * hh * (size_t)REC_SIZE);
+    if (P.rec) { P.A = P.rec + REC_A; P.lxx = P.rec + REC_LXX; P.B = P.rec + REC_B; P.C = P.rec + REC_C; P.D = P.rec + REC_D; P.luu = P.rec + REC_LUU;
+                 P.lyy = P.rec + REC_LYY; P.lx = P.rec + REC_LX; P.lu = P.rec + REC_LU; P.ly = P.rec + REC_LY; }
+    al(&P.l, B * hh); al(&P.lbase, B * hh);
     al(&P.Phi, B); al(&P.Phibase, B); al(&P.Phix, B * 36); al(&P.Phixx, B * 1296); al(&P.H0, B * 1296); al(&P.Px, B * (size_t)P.next_n * 36);
     al(&P.g, B * hh * ng); al(&P.delta, B * hh * ng); al(&P.eps, B * hh * ng);
     al(&P.th, B * P.nt); al(&P.sigma, B * P.nt); al(&P.lambda, B * P.nt);
@@ -111,6 +114,15 @@ inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems)
         case HSDDP_F_H0: count = 1; elems = n * n; return P.H0;
         default: count = 0; elems = 0; return nullptr;
     }
+}
+
+// returns the base pointer of field f; knot record kk of problem b starts at base + (b*count + kk)*stride
+inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems, int& stride) {
+    const double* base = field_dev(P, f, count, elems);
+    const bool in_rec = (f == HSDDP_F_A || f == HSDDP_F_B || f == HSDDP_F_C || f == HSDDP_F_D || f == HSDDP_F_LX || f == HSDDP_F_LU || f == HSDDP_F_LY ||
+                         f == HSDDP_F_LXX || f == HSDDP_F_LUU || f == HSDDP_F_LYY);
+    stride = in_rec ? P.rs : elems;
+    return base;
 }
 
 }  // namespace hs

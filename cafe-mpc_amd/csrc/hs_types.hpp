@@ -5,6 +5,9 @@
 namespace hs {
 
 constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 72;
+// LQ record layout (doubles), whole body 36/12/12
+constexpr int REC_A = 0, REC_LXX = 1536, REC_B = 3072, REC_C = 3584, REC_D = 4096, REC_LUU = 4352, REC_LYY = 4608,
+              REC_LX = 4864, REC_LU = 4900, REC_LY = 4912, REC_SIZE = 4928;
 
 // Per-phase device descriptor.  Trajectory arrays are [batch][count][elems] (problem-major, horizon-major,
 // element-contiguous, matrices column-major) so that one wave reads/writes a knot's record with unit stride.
@@ -30,6 +33,10 @@ struct PhaseDev {
     double *Y;                                                         // h x p
     double *K, *Qux, *Quu;                                             // h x (m*n), h x (m*m)
     double *A, *B, *C, *D;                                             // h x ...
+    // LQ record of a knot: ONE contiguous block per (problem, knot) of `rs` doubles holding A | lxx | B | C | D | luu | lyy |
+    // lx lu ly, each sub-array starting at a multiple of 256 doubles (REC_* offsets), so that the Riccati workgroup
+    // streams a knot with one base pointer and unit stride.  A, lxx, ... below point INTO rec: element e of knot kk is P.A[kk*rs + e].
+    double* rec; int rs;
     double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
     double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
     double *g, *delta, *eps;                                           // h x ng

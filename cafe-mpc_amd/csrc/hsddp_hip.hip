@@ -542,15 +542,17 @@ int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) {
 
 int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) {
     if (!h || phase < 0 || phase >= h->nph || field < 0 || field >= HSDDP_F_COUNT) return HSDDP_EINVAL;
-    field_dev(h->ph[phase], field, *count, *elems); return HSDDP_OK;
+    int stride; field_dev(h->ph[phase], field, *count, *elems, stride); return HSDDP_OK;
 }
 int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
     if (!h || phase < 0 || phase >= h->nph || field < 0 || field >= HSDDP_F_COUNT || b0 < 0 || nb < 0 || b0 + nb > h->batch || !dst) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
-    int count, elems; const double* src = field_dev(h->ph[phase], field, count, elems);
+    int count, elems, stride; const double* src = field_dev(h->ph[phase], field, count, elems, stride);
     const size_t sz = (size_t)count * elems;
     if (!src) { memset(dst, 0, sz * nb * 8); return HSDDP_OK; }
-    HIPCK(hipMemcpy(dst, src + (size_t)b0 * sz, sz * nb * 8, hipMemcpyDeviceToHost));
+    if (sz == 0 || nb == 0) return HSDDP_OK;
+    if (stride == elems) HIPCK(hipMemcpy(dst, src + (size_t)b0 * sz, sz * nb * 8, hipMemcpyDeviceToHost));
+    else HIPCK(hipMemcpy2D(dst, (size_t)elems * 8, src + (size_t)b0 * count * stride, (size_t)stride * 8, (size_t)elems * 8, (size_t)nb * count, hipMemcpyDeviceToHost));
     return HSDDP_OK;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h ? h->solve_ms : 0.f; }

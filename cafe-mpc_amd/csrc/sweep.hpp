@@ -149,11 +149,9 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
 // ---- prefetch of one knot's record (backward sweep): 20 rounds of 256 elements, each round inside ONE array ----
 //   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 C | 16 D | 17 luu | 18 lyy | 19 [lx(36) lu(12) ly(12) Defect[k+1](36)]
 #define SW_RICCATI_FETCH(kk_, k_) { \
-    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; PRE(r) = (e < N * N) ? P.A[(kk_) * N * N + e] : 0.0; PRE(6 + r) = (e < N * N) ? P.lxx[(kk_) * N * N + e] : 0.0; } \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = (e < N * M) ? P.B[(kk_) * N * M + e] : 0.0; PRE(14 + r) = (e < PY * N) ? P.C[(kk_) * PY * N + e] : 0.0; } \
-    PRE(16) = (tid < PY * M) ? P.D[(kk_) * PY * M + tid] : 0.0; PRE(17) = (tid < M * M) ? P.luu[(kk_) * M * M + tid] : 0.0; PRE(18) = (tid < PY * PY) ? P.lyy[(kk_) * PY * PY + tid] : 0.0; \
-    PRE(19) = (tid < N) ? P.lx[(kk_) * N + tid] : (tid < N + M) ? P.lu[(kk_) * M + tid - N] : (tid < N + M + PY) ? P.ly[(kk_) * PY + tid - N - M] \
-            : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
+    const double* rec_ = P.rec + (kk_) * (size_t)REC_SIZE + tid; \
+    _Pragma("unroll") for (int r = 0; r < 19; r++) PRE(r) = rec_[NT * r];     /* sub-arrays start at multiples of 256: one base, constant offsets */ \
+    PRE(19) = (tid < N + M + PY) ? rec_[REC_LX] : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
 #define SW_RICCATI_COMMIT() { \
     _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(6 + r); } } \
     _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; if (e < N * M) S.B[(e % N) + LDN * (e / N)] = PRE(12 + r); if (e < PY * N) S.C[(e % PY) + LDM * (e / PY)] = PRE(14 + r); } \
@@ -163,6 +161,7 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
+    static_assert(REC_LXX == 6 * NT && REC_B == 12 * NT && REC_C == 14 * NT && REC_D == 16 * NT && REC_LUU == 17 * NT && REC_LYY == 18 * NT && REC_LX == 19 * NT && REC_LU == REC_LX + N && REC_LY == REC_LU + M, "record layout");
     static_assert(NT == 256 && N % 3 == 0 && M % 3 == 0 && PY % 3 == 0 && N % 2 == 0 && M % 2 == 0, "tile shapes");
     const int h = P.h;
     SW_PRE_DECL
@@ -277,10 +276,11 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
 // ---- linear rollout: forward over phases/knots; next knot prefetched into 18 registers per thread (dense ld = rows) ----
 //   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 K | 16 luu | 17 [lx(36) lu(12) dU(12) Defect[k+1](36)]
 #define SW_LIN_FETCH(kk_, k_) { \
-    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; PRE(r) = (e < N * N) ? P.A[(kk_) * N * N + e] : 0.0; PRE(6 + r) = (e < N * N) ? P.lxx[(kk_) * N * N + e] : 0.0; } \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = (e < N * M) ? P.B[(kk_) * N * M + e] : 0.0; PRE(14 + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
-    PRE(16) = (tid < M * M) ? P.luu[(kk_) * M * M + tid] : 0.0; \
-    PRE(17) = (tid < N) ? P.lx[(kk_) * N + tid] : (tid < N + M) ? P.lu[(kk_) * M + tid - N] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
+    const double* rec_ = P.rec + (kk_) * (size_t)REC_SIZE + tid; \
+    _Pragma("unroll") for (int r = 0; r < 6; r++) { PRE(r) = rec_[REC_A + NT * r]; PRE(6 + r) = rec_[REC_LXX + NT * r]; } \
+    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = rec_[REC_B + NT * r]; PRE(14 + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
+    PRE(16) = rec_[REC_LUU]; \
+    PRE(17) = (tid < N + M) ? rec_[REC_LX] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
             : (tid < 2 * N + 2 * M) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
 #define SW_LIN_COMMIT() { \
     _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[e] = PRE(r); S.Qxx[e] = PRE(6 + r); } } \

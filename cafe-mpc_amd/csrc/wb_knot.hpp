@@ -548,13 +548,13 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
     HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) {
         const int r = e % 36, c = e / 36;
-        P.A[kk * 1296 + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
+        P.A[kk * P.rs + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
     })
-    store_block<NT>(P.C + kk * 432, L.Jc(), 432);
+    store_block<NT>(P.C + kk * P.rs, L.Jc(), 432);
     HS_PHASE(NT,
-        for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * 432 + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
+        for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
         for (int e = tid; e < 144; e += NT) { const int r = e % 12, j = e / 12, f = r / 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = 3 * t + r % 3;
-            P.D[kk * 144 + e] = (a >= 0) ? -D.Kinv[(18 + a) * 30 + 6 + j] : 0.0; })
+            P.D[kk * P.rs + e] = (a >= 0) ? -D.Kinv[(18 + a) * 30 + 6 + j] : 0.0; })
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
     HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
@@ -574,16 +574,16 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         }
         if (P.go_height >= 0 && d == 2) { lxd += dt * D.bd()[P.go_height]; diag += dt * D.bdd()[P.go_height]; }
         D.W[d * 36 + d] += diag;
-        P.lx[kk * 36 + d] = lxd;
+        P.lx[kk * P.rs + d] = lxd;
     })
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * 1296 + e] = D.W[r * 36 + c]; })
+    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * P.rs + e] = D.W[r * 36 + c]; })
     // lu, luu (diag + torque barrier), ly, lyy (grf barrier 3x3 blocks) staged in Cst (288 of 432)
     HS_PHASE(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
     HS_PHASE(NT, if (tid < 12) {
         const int i = tid;
         double lu = dt * P.r[i] * (L.u[i] - P.ur[(size_t)k * 12 + i]), luu = dt * P.r[i];
         if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }
-        P.lu[kk * 12 + i] = lu; L.Jc()[i + 12 * i] = luu;
+        P.lu[kk * P.rs + i] = lu; L.Jc()[i + 12 * i] = luu;
         // y: grf pyramid rows [0 0 1; -1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu] for foot f = i/3
         double ly = 0.0; const int f = i / 3, r = i % 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = t;
         if (P.go_grf >= 0 && a >= 0) {
@@ -596,10 +596,10 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
                 L.Jc()[144 + (3 * f) + 12 * i] += hb * r0; L.Jc()[144 + (3 * f + 1) + 12 * i] += hb * r1; L.Jc()[144 + (3 * f + 2) + 12 * i] += hb * r2;
             }
         }
-        P.ly[kk * 12 + i] = dt * ly;
+        P.ly[kk * P.rs + i] = dt * ly;
     })
-    store_block<NT>(P.luu + kk * 144, L.Jc(), 144);
-    store_block<NT>(P.lyy + kk * 144, L.Jc() + 144, 144);
+    store_block<NT>(P.luu + kk * P.rs, L.Jc(), 144);
+    store_block<NT>(P.lyy + kk * P.rs, L.Jc() + 144, 144);
 }
 
 // Terminal partials of a phase (+ AL) and the reset-map partial Px (next_n x 36, column-major) if a phase follows.

@@ -105,11 +105,12 @@ int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* a, double* b) { memcpy(
 int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* f) { memcpy(f, h->feas.data(), h->batch * 8); return 0; }
 int hsddp_solve(hsddp_handle_t*, const hsddp_option_t*, float) { return HSDDP_ENOTSUP; }
 int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) { for (int b = 0; b < h->batch; b++) { memset(&info[b], 0, sizeof(info[b])); info[b].actual_cost = h->acost[b]; info[b].dyn_feas = h->feas[b]; } return 0; }
-int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) { field_dev(h->ph[phase], field, *count, *elems); return 0; }
+int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) { int st; field_dev(h->ph[phase], field, *count, *elems, st); return 0; }
 int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
-    int count, elems; const double* src = field_dev(h->ph[phase], field, count, elems); size_t sz = (size_t)count * elems;
+    int count, elems, stride; const double* src = field_dev(h->ph[phase], field, count, elems, stride); size_t sz = (size_t)count * elems;
     if (!src) { memset(dst, 0, sz * nb * 8); return 0; }
-    memcpy(dst, src + (size_t)b0 * sz, sz * nb * 8); return 0;
+    for (size_t r = 0; r < (size_t)nb * count; r++) memcpy(dst + r * elems, src + ((size_t)b0 * count + r) * stride, (size_t)elems * 8);
+    return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
