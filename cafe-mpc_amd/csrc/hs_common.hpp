@@ -15,14 +15,21 @@
 #define HS_PHASE(NT, ...) { for (int tid = 0; tid < (NT); ++tid) { __VA_ARGS__ } }
 // wave-level phase: only the first 64 threads of the workgroup run it, ordered by a wave barrier (no s_barrier)
 #define HS_WPHASE(...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
+#define HS_PHASE_L(NT, ...) HS_PHASE(NT, __VA_ARGS__)
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
 #define HS_SHARED __shared__
-#define HS_PHASE(NT, ...) { { const int tid = threadIdx.x; if (tid < (NT)) { __VA_ARGS__ } } __syncthreads(); }
+#define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); if (tid < (NT)) { __VA_ARGS__ } } __syncthreads(); }
 // wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program
 // order, so the only thing to prevent is compiler motion across the phase boundary.
-#define HS_WPHASE(...) { if (threadIdx.x < 64) { const int tid = threadIdx.x; { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+// LDS-only phase boundary: raw s_barrier behind an lgkmcnt(0) wait.  __syncthreads() carries a workgroup release fence,
+// for which hipcc emits s_waitcnt vmcnt(0) whenever global stores may be pending - that would also drain the
+// prefetch loads that are meant to stay in flight across the knot.  Phases that only hand data over through LDS use this.
+// (tid is laundered through an empty asm so that index arithmetic derived from it is NOT hoisted out of the knot loop and
+// kept live in hundreds of registers / scratch slots)
+#define HS_PHASE_L(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); if (tid < (NT)) { __VA_ARGS__ } } asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#define HS_WPHASE(...) { if (threadIdx.x < 64) { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
 // compiler-only memory barrier: stops the scheduler from hoisting a whole unrolled recurrence's LDS loads ahead of it

@@ -173,12 +173,12 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
     for (int k = h - 1; k >= 0; k--) {
         const size_t kk = (size_t)b * h + k;
         SW_STAMP0()
-        HS_PHASE(NT, SW_RICCATI_COMMIT() if (k > 0) SW_RICCATI_FETCH(kk - 1, k - 1))
+        HS_PHASE_L(NT, SW_RICCATI_COMMIT() if (k > 0) SW_RICCATI_FETCH(kk - 1, k - 1))
         SW_STAMP(0)
         // HA = H A (3x3 tiles) ; HB = H B ; lC = lyy C ; lD = lyy D (3x2 tiles) ; Gnext = G + H Defect[k+1]
         {
             constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (N / 3) * (M / 2), t3 = t2 + (PY > 0 ? (PY / 3) * (N / 2) : 0), t4 = t3 + (PY > 0 ? (PY / 3) * (M / 2) : 0);
-            HS_PHASE(NT,
+            HS_PHASE_L(NT,
                 for (int tile = tid; tile < t4; tile += NT) {
                     if (tile < t1) mm_tile<false, 3, 3, N>(tile, N / 3, S.HA, LDN, S.H, LDN, S.A, LDN, false, 1.0);
                     else if (tile < t2) mm_tile<false, 3, 2, N>(tile - t1, N / 3, S.HB, LDN, S.H, LDN, S.B, LDN, false, 1.0);
@@ -191,7 +191,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         // Qxx += A^T HA (+ C^T lC) ; Qux = B^T HA (+ D^T lC) ; Quu += B^T HB (+ D^T lD) ; Qx += A^T Gn (+C^T ly) ; Qu += B^T Gn (+D^T ly)
         {
             constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (M / 3) * (N / 2);
-            HS_PHASE(NT,
+            HS_PHASE_L(NT,
                 if (tid < t1) { mm_tile<true, 3, 3, N>(tid, N / 3, S.Qxx, LDN, S.A, LDN, S.HA, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 3, (PY > 0 ? PY : 1)>(tid, N / 3, S.Qxx, LDN, S.C, LDM, S.lC, LDM, true, 1.0); }
                 else if (tid < t2) { mm_tile<true, 3, 2, N>(tid - t1, M / 3, S.Qux, LDM, S.B, LDN, S.HA, LDN, false, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid - t1, M / 3, S.Qux, LDM, S.D, LDM, S.lC, LDM, true, 1.0); }
                 else if (tid < t2 + N) {
@@ -201,7 +201,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
                     S.Qx[i] += s;
                 })
             constexpr int u1 = (M / 3) * (M / 2);
-            HS_PHASE(NT,
+            HS_PHASE_L(NT,
                 if (tid < u1) { mm_tile<true, 3, 2, N>(tid, M / 3, S.Quu, LDM, S.B, LDN, S.HB, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid, M / 3, S.Quu, LDM, S.D, LDM, S.lD, LDM, true, 1.0); }
                 else if (tid >= 64 && tid < 64 + M) {
                     const int a = tid - 64; double s = 0;
@@ -212,24 +212,24 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         }
         SW_STAMP(2)
         // regularisation on Quu; store Qu / Quu / Qux as the reference keeps them (callers read them)
-        HS_PHASE(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; })
-        HS_PHASE(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
+        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; })
+        HS_PHASE_L(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
         chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &S.ok);
         HS_WPHASE(if (tid < M) inv_col_w<M, LDM>(S.LQ, S.rdQ, S.Qi, tid);)
         SW_STAMP(4)
-        HS_PHASE(NT,
+        HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) { const int i = e % N, j = e / N; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
         SW_STAMP(5)
         if (!S.ok) return false;
         // K = -Qi Qux ; dU = -Qi Qu
-        HS_PHASE(NT,
+        HS_PHASE_L(NT,
             if (tid < (M / 3) * (N / 2)) mm_tile<false, 3, 2, M>(tid, M / 3, S.K, LDM, S.Qi, LDM, S.Qux, LDM, false, -1.0);
             else if (tid >= NT - M) { const int a = tid - (NT - M); double s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += S.Qi[a * LDM + t] * S.Qu[t]; S.dU[a] = -s; })
         SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
-        HS_PHASE(NT,
+        HS_PHASE_L(NT,
             if (tid < (N / 3) * (N / 3)) {
                 const int ti = tid % (N / 3), tj = tid / (N / 3);
                 _Pragma("unroll") for (int jj = 0; jj < 3; jj++) { _Pragma("unroll") for (int ii = 0; ii < 3; ii++) CM(S.H, 3 * ti + ii, 3 * tj + jj, LDN) = CM(S.Qxx, 3 * ti + ii, 3 * tj + jj, LDN); }
@@ -238,7 +238,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
             else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
-        HS_PHASE(NT, st_mat<NT>(tid, P.K + kk * M * N, S.K, LDM, M, N);)
+        HS_PHASE_L(NT, st_mat<NT>(tid, P.K + kk * M * N, S.K, LDM, M, N);)
         SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
@@ -305,12 +305,12 @@ HD void linear_rollout_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double
                  SW_LIN_FETCH((size_t)b * h, 0))
         for (int k = 0; k < h; k++) {
             const size_t kk = (size_t)b * h + k;
-            HS_PHASE(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
-            HS_PHASE(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
-            HS_PHASE(NT,
+            HS_PHASE_L(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
+            HS_PHASE_L(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
+            HS_PHASE_L(NT,
                 if (tid < N) {
                     double s = 0, q = 0;
-                    _Pragma("unroll") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
+                    _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
                     double s2 = 0;
                     _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(S.B, tid, j, N) * S.du[j];
                     const double v = s + s2 + eps * S.def[tid];
@@ -322,7 +322,7 @@ HD void linear_rollout_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double
                     _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(S.Quu, a, j, M) * S.du[j];
                     S.red[tid] = S.du[a] * q; S.red[64 + tid] = S.Qu[a] * S.du[a];
                 })
-            HS_PHASE(NT, if (tid == 0) {
+            HS_PHASE_L(NT, if (tid == 0) {
                 double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
                 for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
                 for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
