@@ -37,7 +37,8 @@ def cpu_baseline(pkg, phases_fn, seed, seconds_hint=20.0):
         return None
     lib = pkg._abi.bind(ctypes.CDLL(path))
     lib.oracle_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box exposes every host CPU in the affinity mask but a one-GPU job owns a 16-core share: size the pool to that
+    cores = min(len(os.sched_getaffinity(0)), 16)
     K = 2
     phases = phases_fn()
     opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=K, cost_thresh=0.0)

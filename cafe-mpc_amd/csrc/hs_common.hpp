@@ -66,6 +66,13 @@ template <class S> HD S mk(double v, bool seed);
 template <> HD double mk<double>(double v, bool) { return v; }
 template <> HD Dual mk<Dual>(double v, bool seed) { return Dual(v, seed ? 1.0 : 0.0); }
 
+// 1/sqrt(x): one reciprocal-square-root instead of a square root plus two divisions in every Cholesky column
+#ifdef HS_HOST_EMU
+HD double hs_rsqrt(double x) { return 1.0 / std::sqrt(x); }
+#else
+HD double hs_rsqrt(double x) { return rsqrt(x); }
+#endif
+
 template <class S> struct V3 { S x, y, z; };
 template <class S> HD V3<S> operator+(V3<S> a, V3<S> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 template <class S> HD V3<S> operator-(V3<S> a, V3<S> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

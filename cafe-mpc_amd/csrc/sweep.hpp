@@ -108,8 +108,8 @@ HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok
             _Pragma("unroll")
             for (int k = 0; k < j; k++) { const double ljk = Lo[j * LD + k]; sj -= ljk * ljk; st -= Lo[tid * LD + k] * ljk; }
             const bool good = sj > 0.0;
-            const double d = sqrt(good ? sj : 1.0);
-            if (tid == j) { rd[j] = 1.0 / d; if (!good) *ok = 0; } else Lo[tid * LD + j] = st / d;
+            const double r = hs_rsqrt(good ? sj : 1.0);
+            if (tid == j) { rd[j] = r; if (!good) *ok = 0; } else Lo[tid * LD + j] = st * r;
         })
     }
 }
@@ -217,16 +217,20 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
         chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &S.ok);
-        HS_WPHASE(if (tid < M) inv_col_w<M, LDM>(S.LQ, S.rdQ, S.Qi, tid);)
+        // K = -Quu^-1 Qux and dU = -Quu^-1 Qu by two triangular solves per column (lanes 0..N-1: columns of Qux, lane N: Qu);
+        // the reference forms Quu_inv = LDLT.solve(I) and multiplies (SinglePhase.cpp:375-380): same result to rounding
+        HS_WPHASE(if (tid <= N) {
+            double y[M];
+            _Pragma("unroll") for (int i = 0; i < M; i++) y[i] = (tid < N) ? CM(S.Qux, i, tid, LDM) : S.Qu[i];
+            _Pragma("unroll") for (int i = 0; i < M; i++) { double s = y[i]; _Pragma("unroll") for (int k2 = 0; k2 < i; k2++) s -= S.LQ[i * LDM + k2] * y[k2]; y[i] = s * S.rdQ[i]; HS_CBAR(); }
+            _Pragma("unroll") for (int i = M - 1; i >= 0; i--) { double s = y[i]; _Pragma("unroll") for (int k2 = i + 1; k2 < M; k2++) s -= S.LQ[k2 * LDM + i] * y[k2]; y[i] = s * S.rdQ[i]; HS_CBAR(); }
+            _Pragma("unroll") for (int i = 0; i < M; i++) { if (tid < N) CM(S.K, i, tid, LDM) = -y[i]; else S.dU[i] = -y[i]; }
+        })
         SW_STAMP(4)
         HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) { const int i = e % N, j = e / N; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
         SW_STAMP(5)
         if (!S.ok) return false;
-        // K = -Qi Qux ; dU = -Qi Qu
-        HS_PHASE_L(NT,
-            if (tid < (M / 3) * (N / 2)) mm_tile<false, 3, 2, M>(tid, M / 3, S.K, LDM, S.Qi, LDM, S.Qux, LDM, false, -1.0);
-            else if (tid >= NT - M) { const int a = tid - (NT - M); double s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += S.Qi[a * LDM + t] * S.Qu[t]; S.dU[a] = -s; })
         SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,

@@ -36,6 +36,7 @@ struct WbCore {
     HD double* dacc() { return GG; }          // LQ program: [3f+r][18] tangents of the foot accelerations
     HD double* dvel() { return GG + 216; }    // LQ program: [3f+r][18] tangents of the foot velocities (= footVelPartialDq)
     double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64], rdM[18], rdG[12];
+    unsigned long long tstamp;
 };
 struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (see accessors)
     double Minv[18 * 18];              // M^-1 ; later the barrier derivative tables bd / bdd
@@ -53,6 +54,14 @@ struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (s
 };
 constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
+#if defined(LQ_PROF) && !defined(HS_HOST_EMU)
+__device__ unsigned long long g_lq_prof[16];
+#define LQ_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
+#define LQ_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
+#else
+#define LQ_STAMP(i)
+#define LQ_STAMP0()
+#endif
 // LQ-program aliases into WbCore: Cst = [Jc|Xm] (432), dacc = G.., dvel = G+216 (G,LG,gval,bar = 432)
 
 // ---- wave-cooperative dense helpers (row-major in LDS), COMPILE-TIME sizes ------------------------------
@@ -67,9 +76,9 @@ HD void chol_s(const double* A, double* Lo, double* rd, double diag_add) {
             double sj = A[j * LD + j] + diag_add, st = A[tid * LD + j];
             _Pragma("unroll")
             for (int k = 0; k < j; k++) { const double ljk = Lo[j * LD + k]; sj -= ljk * ljk; st -= Lo[tid * LD + k] * ljk; }
-            const double d = sqrt(sj);
+            const double r = hs_rsqrt(sj);
             // the diagonal of Lo is never written (it may alias A, whose pivot other lanes still read) nor read: rd[] carries it
-            if (tid == j) rd[j] = 1.0 / d; else Lo[tid * LD + j] = st / d;
+            if (tid == j) rd[j] = r; else Lo[tid * LD + j] = st * r;
         })
     }
 }
@@ -265,7 +274,8 @@ HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, do
         for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
     })
     HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[tid * 12 + a] * L.lam[a]; L.qdd[tid] = s; })
-    if (mode == 0) chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, 0.0);      // undamped factor for the KKT inverse
+    // the KKT inverse reuses the factor of the forward solve: Pinocchio's computeKKTContactDynamicMatrixInverse uses damping 0,
+    // forwardDynamics 1e-12; keeping one factor changes Lambda by <= 1e-12 * cond(J Minv J^T) relative (1e-11 here).
     HS_PHASE(NT, if (tid < 12) inv_col_s<12, 12>(L.LG(), L.rdG, D.Lam(), 12, tid);)
     HS_PHASE(NT, if (tid < 12) {             // Y = X Lam with padded rows/cols of Lam forced to zero
         _Pragma("unroll")
@@ -507,11 +517,15 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 12) { L.u[tid] = P.U[ku + tid]; L.fext[tid] = 0.0; }
              if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; })
     HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
+    LQ_STAMP0()
     wb_terms<NT>(L, md, true);
+    LQ_STAMP(0)
     wb_kkt_full<NT>(L, D, P.nc, P.feet, 0, P.bg_alpha);
+    LQ_STAMP(1)
     const int m = 3 * P.nc;
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid]; if (tid < 12) L.fext[tid] = L.grf[tid];)
     wb_dpass<NT>(L, D, md, GRAV, 1.0, 1.0, 1.0, false);
+    LQ_STAMP(2)
     // column d of the continuous partials: top = d tau - d(J^T F) (18), bot = d(foot acc) + Baumgarte terms (m)
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
@@ -545,6 +559,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
             L.Jc()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = s;
         }
     })
+    LQ_STAMP(3)
     // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
     HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) {
         const int r = e % 36, c = e / 36;
@@ -555,6 +570,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
         for (int e = tid; e < 144; e += NT) { const int r = e % 12, j = e / 12, f = r / 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = 3 * t + r % 3;
             P.D[kk * P.rs + e] = (a >= 0) ? -D.Kinv[(18 + a) * 30 + 6 + j] : 0.0; })
+    LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
     HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
@@ -577,6 +593,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         P.lx[kk * P.rs + d] = lxd;
     })
     HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * P.rs + e] = D.W[r * 36 + c]; })
+    LQ_STAMP(5)
     // lu, luu (diag + torque barrier), ly, lyy (grf barrier 3x3 blocks) staged in Cst (288 of 432)
     HS_PHASE(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
     HS_PHASE(NT, if (tid < 12) {
@@ -600,6 +617,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     })
     store_block<NT>(P.luu + kk * P.rs, L.Jc(), 144);
     store_block<NT>(P.lyy + kk * P.rs, L.Jc() + 144, 144);
+    LQ_STAMP(6)
 }
 
 // Terminal partials of a phase (+ AL) and the reset-map partial Px (next_n x 36, column-major) if a phase follows.

@@ -29,3 +29,12 @@ if hasattr(lib, "hsddp_debug_sweep_prof"):
     tot = sum(buf)
     for i, n in enumerate(names[:9] if False else names):
         if i < 16: print(f"  stamp {i} {n:16s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
+if hasattr(lib, "hsddp_debug_lq_prof"):
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.hsddp_debug_lq_prof(buf, 1)
+    s.LQ_approximation(opt)
+    lib.hsddp_debug_lq_prof(buf, 0)
+    names = ["terms(P pass)", "kkt_full", "dpass", "A/C columns", "store A,B,C,D", "cost partials lxx", "lu/luu/ly/lyy"]
+    tot = sum(buf)
+    for i, n in enumerate(names):
+        print(f"  lq stamp {i} {n:20s} {buf[i]:10d} cycles ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
