@@ -98,6 +98,37 @@ HD void mm_tile(int tile, int nti, double* C, int ldc, const double* A, int lda,
     }
 }
 
+// One 16x16 output tile per WAVE on the fp64 matrix cores:  Cout(i,j) = (Cin ? Cin(i,j) : 0) + sum_t opA(i,t) * B(t,j)
+// (v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns C rows (l>>4) + 4r, column l&15).
+// Each MFMA performs 1024 FMAs from 2 LDS reads per lane (1 B/FMA); the 3x3 VALU register tile needs 5.3 B/FMA and was
+// LDS-bandwidth bound.  Rows/cols beyond M_/N_ (36 = 2.25 tiles) are fed zeros / not stored.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <bool TA, int K>
+HD void mfma_tile(int lane, double* Cout, int ldc, const double* Cin, int ldcin, int i0, int j0, int M_, int N_,
+                  const double* A, int lda, const double* B, int ldb) {
+#ifdef HS_HOST_EMU
+    if (lane != 0) return;     // the emulator lets lane 0 stand for the wave (plain loops); the lane mapping is verified on the GPU
+    for (int j = j0; j < j0 + 16 && j < N_; j++) for (int i = i0; i < i0 + 16 && i < M_; i++) {
+        double s = Cin ? Cin[i + ldcin * j] : 0.0;
+        for (int t = 0; t < K; t++) s += (TA ? A[t + lda * i] : A[i + lda * t]) * B[t + ldb * j];
+        Cout[i + ldc * j] = s;
+    }
+#else
+    static_assert(K % 4 == 0, "K must be a multiple of 4");
+    const int li = lane & 15, lk = lane >> 4, i = i0 + li, j = j0 + li;
+    const bool iv = i < M_, jv = j < N_;
+    d4_t c;
+    _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; c[r] = (Cin && row < M_ && jv) ? Cin[row + ldcin * j] : 0.0; }
+    _Pragma("unroll") for (int kg = 0; kg < K / 4; kg++) {
+        const int k = 4 * kg + lk;
+        const double a = iv ? (TA ? A[k + lda * i] : A[i + lda * k]) : 0.0;
+        const double b = jv ? B[k + ldb * j] : 0.0;
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < M_ && jv) Cout[row + ldc * j] = c[r]; }
+#endif
+}
+
 // ---- wave-level (wave 0) factorisation helpers, compile-time size, recurrences in registers -------------------
 template <int N, int LD>
 HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok) {
@@ -175,44 +206,53 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         SW_STAMP0()
         HS_PHASE_L(NT, SW_RICCATI_COMMIT() if (k > 0) SW_RICCATI_FETCH(kk - 1, k - 1))
         SW_STAMP(0)
-        // HA = H A (3x3 tiles) ; HB = H B ; lC = lyy C ; lD = lyy D (3x2 tiles) ; Gnext = G + H Defect[k+1]
-        {
-            constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (N / 3) * (M / 2), t3 = t2 + (PY > 0 ? (PY / 3) * (N / 2) : 0), t4 = t3 + (PY > 0 ? (PY / 3) * (M / 2) : 0);
-            HS_PHASE_L(NT,
-                for (int tile = tid; tile < t4; tile += NT) {
-                    if (tile < t1) mm_tile<false, 3, 3, N>(tile, N / 3, S.HA, LDN, S.H, LDN, S.A, LDN, false, 1.0);
-                    else if (tile < t2) mm_tile<false, 3, 2, N>(tile - t1, N / 3, S.HB, LDN, S.H, LDN, S.B, LDN, false, 1.0);
-                    else if (tile < t3) mm_tile<false, 3, 2, (PY > 0 ? PY : 1)>(tile - t2, PY / 3, S.lC, LDM, S.lyy, LDM, S.C, LDM, false, 1.0);
-                    else mm_tile<false, 3, 2, (PY > 0 ? PY : 1)>(tile - t3, PY / 3, S.lD, LDM, S.lyy, LDM, S.D, LDM, false, 1.0);
-                }
-                if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.G[i]; _Pragma("unroll") for (int j = 0; j < N; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; })
-        }
+        // phase 1 (matrix cores, 30 MFMAs per wave): HA = H A (9 tiles: waves 0-2) ; HB = H B (3 tiles: wave 3) ;
+        // lC = lyy C (3 tiles: waves 1-3) ; lD = lyy D (wave 0) ; Gnext = G + H Defect[k+1]
+        HS_PHASE_L(NT, {
+            const int w = tid >> 6, lane = tid & 63;
+            if (w < 3) { for (int t = 0; t < 3; t++) { const int tile = 3 * w + t; mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (tile % 3), 16 * (tile / 3), N, N, S.H, LDN, S.A, LDN); } }
+            else { for (int t = 0; t < 3; t++) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * t, 0, N, M, S.H, LDN, S.B, LDN); }
+            if (PY > 0) {
+                if (w == 0) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 0, 0, PY, M, S.lyy, LDM, S.D, LDM);
+                else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 0, 16 * (w - 1), PY, N, S.lyy, LDM, S.C, LDM);
+            }
+            if (tid < N) { double s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
+        })
         SW_STAMP(1)
-        // Qxx += A^T HA (+ C^T lC) ; Qux = B^T HA (+ D^T lC) ; Quu += B^T HB (+ D^T lD) ; Qx += A^T Gn (+C^T ly) ; Qu += B^T Gn (+D^T ly)
-        {
-            constexpr int t1 = (N / 3) * (N / 3), t2 = t1 + (M / 3) * (N / 2);
-            HS_PHASE_L(NT,
-                if (tid < t1) { mm_tile<true, 3, 3, N>(tid, N / 3, S.Qxx, LDN, S.A, LDN, S.HA, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 3, (PY > 0 ? PY : 1)>(tid, N / 3, S.Qxx, LDN, S.C, LDM, S.lC, LDM, true, 1.0); }
-                else if (tid < t2) { mm_tile<true, 3, 2, N>(tid - t1, M / 3, S.Qux, LDM, S.B, LDN, S.HA, LDN, false, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid - t1, M / 3, S.Qux, LDM, S.D, LDM, S.lC, LDM, true, 1.0); }
-                else if (tid < t2 + N) {
-                    const int i = tid - t2; double s = 0;
-                    _Pragma("unroll") for (int t = 0; t < N; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
-                    if (PY > 0) { _Pragma("unroll") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
-                    S.Qx[i] += s;
-                })
-            constexpr int u1 = (M / 3) * (M / 2);
-            HS_PHASE_L(NT,
-                if (tid < u1) { mm_tile<true, 3, 2, N>(tid, M / 3, S.Quu, LDM, S.B, LDN, S.HB, LDN, true, 1.0); if (PY > 0) mm_tile<true, 3, 2, (PY > 0 ? PY : 1)>(tid, M / 3, S.Quu, LDM, S.D, LDM, S.lD, LDM, true, 1.0); }
-                else if (tid >= 64 && tid < 64 + M) {
-                    const int a = tid - 64; double s = 0;
-                    _Pragma("unroll") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
-                    if (PY > 0) { _Pragma("unroll") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
-                    S.Qu[a] += s;
-                } else if (tid >= 128 && tid < 128 + N) CM(S.Qxx, tid - 128, tid - 128, LDN) += reg;)     // regularisation on Qxx: quirk x
-        }
+        // phase 2: Qxx += A^T HA + C^T lC (9 tiles: waves 0-2) ; Qux = B^T HA + D^T lC (3 tiles) and Quu += B^T HB + D^T lD (wave 3) ;
+        // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
+        HS_PHASE_L(NT, {
+            const int w = tid >> 6, lane = tid & 63;
+            if (w < 3) {
+                for (int t = 0; t < 3; t++) {
+                    const int tile = 3 * w + t, i0 = 16 * (tile % 3), j0 = 16 * (tile / 3);
+                    mfma_tile<true, N>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.A, LDN, S.HA, LDN);
+                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.C, LDM, S.lC, LDM);
+                }
+            } else {
+                for (int t = 0; t < 3; t++) {
+                    mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, 0, 16 * t, M, N, S.B, LDN, S.HA, LDN);
+                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, 0, 16 * t, M, N, S.D, LDM, S.lC, LDM);
+                }
+                mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, 0, 0, M, M, S.B, LDN, S.HB, LDN);
+                if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, 0, 0, M, M, S.D, LDM, S.lD, LDM);
+            }
+            if (tid < N) {
+                double s = 0;
+                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, tid, LDN) * S.Gn[t];
+                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, tid, LDM) * S.ly[t]; }
+                S.Qx[tid] += s;
+            } else if (tid >= 64 && tid < 64 + M) {
+                const int a = tid - 64; double s = 0;
+                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
+                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
+                S.Qu[a] += s;
+            }
+        })
         SW_STAMP(2)
         // regularisation on Quu; store Qu / Quu / Qux as the reference keeps them (callers read them)
-        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; })
+        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; }
+                   else if (tid >= 64 && tid < 64 + N) CM(S.Qxx, tid - 64, tid - 64, LDN) += reg;)     // regularisation on Qxx as well: quirk x
         HS_PHASE_L(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
@@ -234,11 +274,9 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
-            if (tid < (N / 3) * (N / 3)) {
-                const int ti = tid % (N / 3), tj = tid / (N / 3);
-                _Pragma("unroll") for (int jj = 0; jj < 3; jj++) { _Pragma("unroll") for (int ii = 0; ii < 3; ii++) CM(S.H, 3 * ti + ii, 3 * tj + jj, LDN) = CM(S.Qxx, 3 * ti + ii, 3 * tj + jj, LDN); }
-                mm_tile<true, 3, 3, M>(tid, N / 3, S.H, LDN, S.Qux, LDM, S.K, LDM, true, 1.0);
-            } else if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
+            { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
+              for (int tile = w; tile < 9; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % 3), 16 * (tile / 3), N, N, S.Qux, LDM, S.K, LDM); }
+            if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
             else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
