@@ -493,18 +493,32 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
 }
 // column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  added to out[0..35], and the gradient entry
 HD double wb_cost_column(WbDeriv& D, int d, double* colout /* stride 36 */) {
-    double tp[12], tw[12];
-        _Pragma("unroll")
-    for (int r = 0; r < 12; r++) { tp[r] = D.wp[r] * D.JP()[r * 36 + d]; tw[r] = D.wv[r] * D.JW()[r * 36 + d]; }
+    // foot by foot; a foot's position-type rows (foot-place reg / swing pos) only touch columns 3..17, its velocity-type rows
+    // (swing vel / touchdown vel) exist only for swing or touchdown feet: the activity tests are uniform over the wave, so
+    // a stance knot skips the 36x36 velocity blocks entirely.
+    double acc[36];
+    _Pragma("unroll")
+    for (int i = 0; i < 36; i++) acc[i] = 0.0;
     double g = 0;
-        _Pragma("unroll")
-    for (int r = 0; r < 12; r++) g += tp[r] * D.ep[r] + tw[r] * D.ev[r];
-    for (int i = 0; i < 36; i++) {
-        double s = 0;
-        _Pragma("unroll")
-        for (int r = 0; r < 12; r++) s += D.JP()[r * 36 + i] * tp[r] + D.JW()[r * 36 + i] * tw[r];
-        colout[i * 36] += s;
+    for (int f = 0; f < 4; f++) {
+        const double* wp = D.wp + 3 * f; const double* wv = D.wv + 3 * f;
+        if (wp[0] != 0.0 || wp[1] != 0.0 || wp[2] != 0.0) {
+            const double* J0 = D.JP() + (3 * f) * 36; const double* J1 = J0 + 36; const double* J2 = J1 + 36;
+            const double t0 = wp[0] * J0[d], t1 = wp[1] * J1[d], t2 = wp[2] * J2[d];
+            g += t0 * D.ep[3 * f] + t1 * D.ep[3 * f + 1] + t2 * D.ep[3 * f + 2];
+            _Pragma("unroll")
+            for (int i = 3; i < 18; i++) acc[i] += J0[i] * t0 + J1[i] * t1 + J2[i] * t2;
+        }
+        if (wv[0] != 0.0 || wv[1] != 0.0 || wv[2] != 0.0) {
+            const double* J0 = D.JW() + (3 * f) * 36; const double* J1 = J0 + 36; const double* J2 = J1 + 36;
+            const double t0 = wv[0] * J0[d], t1 = wv[1] * J1[d], t2 = wv[2] * J2[d];
+            g += t0 * D.ev[3 * f] + t1 * D.ev[3 * f + 1] + t2 * D.ev[3 * f + 2];
+            _Pragma("unroll")
+            for (int i = 0; i < 36; i++) acc[i] += J0[i] * t0 + J1[i] * t1 + J2[i] * t2;
+        }
     }
+    _Pragma("unroll")
+    for (int i = 0; i < 36; i++) colout[i * 36] += acc[i];
     return g;
 }
 
