@@ -1,7 +1,7 @@
 """ctypes mirror of include/hsddp.h (struct layouts + prototypes).
 
 Used by the product wrapper (`MultiPhaseDDP` in __init__.py, bound to libhsddp_hip.so) and by the
-tests to drive oracle/liboracle_hsddp.so through the *same* ABI.  Nothing here computes anything.
+tests to drive the CPU checker library through the *same* ABI (the tests pass its path in).  Nothing here computes anything.
 """
 import ctypes as C
 import numpy as np

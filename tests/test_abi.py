@@ -1,0 +1,68 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/hsddp.h declares
+(no compute calls: there is no GPU here), the ctypes struct mirrors match the C layouts, and the product wrapper
+refuses to run without the HIP library (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import pkg, ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "hsddp.h")).read()
+    return sorted(set(re.findall(r"\b(hsddp_[a-zA-Z_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_match_binding_list():
+    assert _declared_symbols() == sorted(pkg._abi.EXPORTS)
+
+
+@pytest.mark.parametrize("which", ["hip", "oracle"])
+def test_library_exports_every_declared_symbol(which):
+    path = pkg.HIP_LIB_PATH if which == "hip" else os.path.join(ROOT, "oracle", "liboracle_hsddp.so")
+    if not os.path.exists(path):
+        if which == "hip":
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "cafe-mpc_amd", "csrc")])
+        else:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(path)
+    for s in _declared_symbols():
+        assert hasattr(lib, s), f"{path} lacks {s}"
+
+
+def test_struct_layouts_match_c(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hsddp.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(hsddp_option_t), '
+                   'sizeof(hsddp_phase_desc_t), sizeof(hsddp_info_t), offsetof(hsddp_phase_desc_t, xr), offsetof(hsddp_phase_desc_t, al_td), sizeof(hsddp_model_param_t));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    A = pkg._abi
+    assert got == [ctypes.sizeof(A.Option), ctypes.sizeof(A.PhaseDesc), ctypes.sizeof(A.Info), A.PhaseDesc.xr.offset, A.PhaseDesc.al_td.offset,
+                   ctypes.sizeof(A.ModelParam)]
+
+
+def test_cpp_host_mirror_compiles(tmp_path):
+    """cafe-mpc_amd/host/MultiPhaseDDP.hpp (the C++ mirror of the reference class) compiles and links against the C-ABI."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "MultiPhaseDDP.hpp"\nint main(){ hsddp::MultiPhaseDDP<double> s(1, 0); auto o = hsddp::default_option(); (void)o; return s.last_error(); }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cafe-mpc_amd", "host"), str(src),
+                           "-L", os.path.join(ROOT, "oracle"), "-loracle_hsddp", "-fopenmp", "-o", str(tmp_path / "t")])
+
+
+def test_no_cpu_fallback_when_hip_library_missing(monkeypatch, tmp_path):
+    monkeypatch.setattr(pkg, "HIP_LIB_PATH", str(tmp_path / "missing.so"))
+    monkeypatch.setattr(pkg, "_lib", None)
+    with pytest.raises(RuntimeError):
+        pkg.MultiPhaseDDP(pkg.problems.wb_stance_problem(horizon=2), batch=1)
+
+
+def test_product_never_references_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cafe-mpc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "oracle/" not in txt.replace("the oracle / ", ""), (dirpath, f)

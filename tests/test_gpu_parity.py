@@ -96,3 +96,60 @@ def test_batch_independence_and_full_size_properties(hip_lib):
     info = s.info_arrays()
     assert (info["status"] == 0).all() and (info["n_iters"] == 3).all()
     assert (info["dyn_feas"] < 0.5).all()       # started at ~6: multiple-shooting defects are being closed
+
+
+def test_flight_phase_and_four_foot_touchdown(hip_lib, oracle_lib):
+    """Barrel-roll-like schedule (BarrelRollTO.cpp:70-81 shape): stance -> flight (no contact: free-fall dynamics,
+    no GRF constraints) -> stance, i.e. a four-foot touchdown (12-row impulse, the mis-sliced impulse of quirk v)."""
+    phases = pkg.problems.wb_trot_problem(schedule=((1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 1, 1)), horizons=(5, 6, 5), last_next=(1, 1, 1, 1))
+    x0 = pkg.problems.wb_ensemble_x0(2, 31)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    pc.run_steps(pkg, so, sg, phases, pkg.mhpc_ddp_setting(), n_iter=2)
+
+
+def test_single_knot_phases_batch_one(hip_lib, oracle_lib):
+    """Smallest shapes: one knot per phase, one problem."""
+    phases = pkg.problems.wb_trot_problem(schedule=((0, 1, 1, 0), (1, 0, 0, 1)), horizons=(1, 1), last_next=(0, 1, 1, 0))
+    x0 = pkg.problems.wb_ensemble_x0(1, 77)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    pc.run_steps(pkg, so, sg, phases, pkg.mhpc_ddp_setting(), n_iter=2)
+
+
+def test_al_and_reb_switched_off(hip_lib, oracle_lib):
+    phases = pkg.problems.wb_trot_problem(horizons=(6, 6, 6, 6))
+    x0 = pkg.problems.wb_ensemble_x0(2, 5)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3, AL_active=0, ReB_active=0)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
+
+
+def test_regularisation_retry_gpu(hip_lib, oracle_lib):
+    """Indefinite Quu at reg = 0 (negative control weights): the in-kernel retry loop of k_sweep must walk the same
+    regularisation schedule as MultiPhaseDDP::backward_sweep_regularized."""
+    phases = pkg.problems.wb_stance_problem(horizon=6)
+    for i in range(12):
+        phases[0]["desc"].r[i] = -50.0
+    x0 = pkg.problems.wb_ensemble_x0(2, 9)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    opt = pkg.mhpc_ddp_setting(ReB_active=0)
+    for s in (so, sg):
+        s.hybrid_rollout(0.0, opt); s.update_nominal_trajectory(); s.compute_cost(opt); s.LQ_approximation(opt)
+    assert not so.backward_sweep(0.0).any() and not sg.backward_sweep(0.0).any()
+    opt1 = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=1, ReB_active=0)
+    so.solve(opt1); sg.solve(opt1)
+    a, b = so.info_arrays(), sg.info_arrays()
+    assert np.array_equal(a["n_reg_iters"], b["n_reg_iters"]) and (a["n_reg_iters"] > 1).all()
+    assert np.array_equal(a["status"], b["status"])
+
+
+def test_unsupported_configurations_fail_loudly(hip_lib):
+    import ctypes
+    phases = pkg.problems.wb_stance_problem(horizon=3)
+    s = pkg.Solver(hip_lib, phases, batch=1)
+    s.set_nominal(0, phases[0]["Xbar"], phases[0]["Ubar"]); s.set_initial_condition(pkg.problems.wb_nominal_state()[None])
+    with pytest.raises(RuntimeError):
+        s.solve(pkg.mhpc_ddp_setting(MS=0))              # single shooting: HSDDP_ENOTSUP, never a silent fallback
+    phases[0]["desc"].model = pkg.MODEL_HKD
+    with pytest.raises(RuntimeError):
+        pkg.Solver(hip_lib, phases, batch=1)
