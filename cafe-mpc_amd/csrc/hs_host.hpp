@@ -22,14 +22,16 @@ inline int constraint_group(const PhaseDev& P, int c) {
 template <class Mem>
 int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t* next, bool is_last, size_t B, PhaseDev& P, int slot0) {
     std::memset(&P, 0, sizeof(P));
-    P.model = d.model; P.n = 36; P.m = 12; P.p = 12; P.h = d.horizon; P.dt = d.dt; P.bg_alpha = d.BG_alpha;
+    P.model = d.model; P.h = d.horizon; P.dt = d.dt; P.bg_alpha = d.BG_alpha;
+    if (d.model == HSDDP_MODEL_WB) { P.n = 36; P.m = 12; P.p = 12; } else if (d.model == HSDDP_MODEL_SRB) { P.n = 12; P.m = 12; P.p = 0; } else { P.n = 24; P.m = 24; P.p = 0; }
+    const size_t n = P.n, m = P.m, py = P.p;
     for (int l = 0; l < 4; l++) {
         P.contact[l] = d.contact[l]; P.next_contact[l] = d.next_contact[l];
         if (d.contact[l] > 0) P.feet[P.nc++] = l;
         P.td[l] = (d.contact[l] == 0 && d.next_contact[l] == 1) ? 1 : 0; P.n_td += P.td[l];
     }
     P.has_impact = P.n_td > 0; P.next_model = d.next_model; P.shooting = d.shooting; P.is_last = is_last ? 1 : 0;
-    P.next_n = next ? (next->model == HSDDP_MODEL_WB ? 36 : next->model == HSDDP_MODEL_SRB ? 12 : 24) : 36;
+    P.next_n = next ? (next->model == HSDDP_MODEL_WB ? 36 : next->model == HSDDP_MODEL_SRB ? 12 : 24) : P.n;
     std::memcpy(P.q, d.q, sizeof(P.q)); std::memcpy(P.r, d.r, sizeof(P.r)); std::memcpy(P.qf, d.qf, sizeof(P.qf));
     std::memcpy(P.w_foot_reg, d.w_foot_reg, 24); std::memcpy(P.w_swing_pos, d.w_swing_pos, 24); std::memcpy(P.w_swing_vel, d.w_swing_vel, 24);
     P.w_td_vel = d.w_td_vel;
@@ -40,31 +42,38 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     for (int g = 0; g < 4; g++) { P.reb_init[g][0] = rb[g]->delta; P.reb_init[g][1] = rb[g]->delta_min; P.reb_init[g][2] = rb[g]->eps; }
     P.al_init[0] = d.al_td.sigma; P.al_init[1] = d.al_td.lambda; P.al_init[2] = d.al_td.sigma_max;
     int ng = 0; P.go_torque = P.go_joint = P.go_height = P.go_grf = -1;
-    if (d.c_torque) { P.go_torque = ng; ng += 24; }
-    if (d.c_joint) { P.go_joint = ng; ng += 24; }
+    const bool wb = d.model == HSDDP_MODEL_WB;
+    if (wb && d.c_torque) { P.go_torque = ng; ng += 24; }
+    if (wb && d.c_joint) { P.go_joint = ng; ng += 24; }
     if (d.c_minheight) { P.go_height = ng; ng += 1; }
-    if (d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
-    P.ng = ng; P.nt = d.c_touchdown ? P.n_td : 0; P.slot0 = slot0;
+    if (wb && d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
+    if (!wb) { P.n_td = 0; P.has_impact = 0; for (int l = 0; l < 4; l++) P.td[l] = 0; }
+    P.ng = ng; P.nt = (wb && d.c_touchdown) ? P.n_td : 0; P.slot0 = slot0;
     const size_t h1 = P.h + 1, hh = P.h;
     bool ok = true;
     auto up = [&](const double** dst, const double* src, size_t cnt) { void* p = mem.alloc(cnt * 8); if (!p) { ok = false; return; } if (src) mem.upload(p, src, cnt * 8); *dst = (const double*)p; };
-    up(&P.xr, d.xr, h1 * 36); up(&P.ur, d.ur, h1 * 12); up(&P.yr, d.yr, h1 * 12);
+    up(&P.xr, d.xr, h1 * n); up(&P.ur, d.ur, h1 * m); up(&P.yr, py ? d.yr : nullptr, h1 * std::max<size_t>(py, 1));
     up(&P.foot_pos, d.foot_pos, h1 * 12); up(&P.foot_vel, d.foot_vel, h1 * 12); up(&P.body_pos, d.body_pos, h1 * 3);
     { void* p = mem.alloc(h1 * 4 * sizeof(int)); if (!p) ok = false; else { if (d.ref_contact) mem.upload(p, d.ref_contact, h1 * 4 * sizeof(int)); P.ref_contact = (const int*)p; } }
     auto al = [&](double** dst, size_t cnt) { void* p = mem.alloc(std::max<size_t>(cnt, 1) * 8); if (!p) ok = false; *dst = (double*)p; };
     double** sx[] = {&P.X, &P.Xbar, &P.Xsim, &P.Defect, &P.Defect_bar, &P.dX, &P.G};
-    for (auto p : sx) al(p, B * h1 * 36);
-    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu, &P.Y};
-    for (auto p : su) al(p, B * hh * 12);
-    double** s432[] = {&P.K, &P.Qux};
-    for (auto p : s432) al(p, B * hh * 432);
-    double** s144[] = {&P.Quu};
-    for (auto p : s144) al(p, B * hh * 144);
-    P.rs = REC_SIZE; al(&P.rec, B * hh * (size_t)REC_SIZE);
-    if (P.rec) { P.A = P.rec + REC_A; P.lxx = P.rec + REC_LXX; P.B = P.rec + REC_B; P.C = P.rec + REC_C; P.D = P.rec + REC_D; P.luu = P.rec + REC_LUU;
-                 P.lyy = P.rec + REC_LYY; P.lx = P.rec + REC_LX; P.lu = P.rec + REC_LU; P.ly = P.rec + REC_LY; }
+    for (auto p : sx) al(p, B * h1 * n);
+    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu};
+    for (auto p : su) al(p, B * hh * m);
+    al(&P.Y, B * hh * py);
+    double** smn[] = {&P.K, &P.Qux};
+    for (auto p : smn) al(p, B * hh * m * n);
+    al(&P.Quu, B * hh * m * m);
+    {   // record layout: the runtime twin of RecLayout<N,M,PY> (hs_types.hpp)
+        auto rnd = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t oA = 0, oLxx = oA + rnd(n * n), oB = oLxx + rnd(n * n), oC = oB + rnd(n * m), oD = oC + rnd(py * n), oLuu = oD + rnd(py * m),
+                     oLyy = oLuu + rnd(m * m), oLx = oLyy + rnd(py * py), oLu = oLx + n, oLy = oLu + m, size = oLx + rnd(n + m + py);
+        P.rs = (int)size; al(&P.rec, B * hh * size);
+        if (P.rec) { P.A = P.rec + oA; P.lxx = P.rec + oLxx; P.B = P.rec + oB; P.C = P.rec + oC; P.D = P.rec + oD; P.luu = P.rec + oLuu;
+                     P.lyy = P.rec + oLyy; P.lx = P.rec + oLx; P.lu = P.rec + oLu; P.ly = P.rec + oLy; }
+    }
     al(&P.l, B * hh); al(&P.lbase, B * hh);
-    al(&P.Phi, B); al(&P.Phibase, B); al(&P.Phix, B * 36); al(&P.Phixx, B * 1296); al(&P.H0, B * 1296); al(&P.Px, B * (size_t)P.next_n * 36);
+    al(&P.Phi, B); al(&P.Phibase, B); al(&P.Phix, B * n); al(&P.Phixx, B * n * n); al(&P.H0, B * n * n); al(&P.Px, B * (size_t)P.next_n * n);
     al(&P.g, B * hh * ng); al(&P.delta, B * hh * ng); al(&P.eps, B * hh * ng);
     al(&P.th, B * P.nt); al(&P.sigma, B * P.nt); al(&P.lambda, B * P.nt);
     if (!ok) return HSDDP_ENOMEM;

@@ -5,9 +5,18 @@
 namespace hs {
 
 constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 72;
-// LQ record layout (doubles), whole body 36/12/12
-constexpr int REC_A = 0, REC_LXX = 1536, REC_B = 3072, REC_C = 3584, REC_D = 4096, REC_LUU = 4352, REC_LYY = 4608,
-              REC_LX = 4864, REC_LU = 4900, REC_LY = 4912, REC_SIZE = 4928;
+// LQ record layout (doubles) of one knot for a model with dims (N, M, PY): every sub-array starts at a multiple of 256
+// doubles so that a 256-thread workgroup streams the record in rounds that each lie inside ONE sub-array.
+//   A | lxx | B | C | D | luu | lyy | [lx lu ly]
+constexpr int rec_rnd(int x) { return (x + 255) / 256 * 256; }
+template <int N, int M, int PY> struct RecLayout {
+    static constexpr int oA = 0, oLxx = oA + rec_rnd(N * N), oB = oLxx + rec_rnd(N * N), oC = oB + rec_rnd(N * M), oD = oC + rec_rnd(PY * N),
+                         oLuu = oD + rec_rnd(PY * M), oLyy = oLuu + rec_rnd(M * M), oLx = oLyy + rec_rnd(PY * PY), oLu = oLx + N, oLy = oLu + M,
+                         size = oLx + rec_rnd(N + M + PY);
+    static constexpr int rA = rec_rnd(N * N) / 256, rB = rec_rnd(N * M) / 256, rC = rec_rnd(PY * N) / 256, rD = rec_rnd(PY * M) / 256,
+                         rLuu = rec_rnd(M * M) / 256, rLyy = rec_rnd(PY * PY) / 256;
+    static constexpr int rounds = 2 * rA + rB + rC + rD + rLuu + rLyy;   // + 1 round for the vectors
+};
 
 // Per-phase device descriptor.  Trajectory arrays are [batch][count][elems] (problem-major, horizon-major,
 // element-contiguous, matrices column-major) so that one wave reads/writes a knot's record with unit stride.

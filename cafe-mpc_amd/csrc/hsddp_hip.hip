@@ -16,6 +16,7 @@
 #include "hs_types.hpp"
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
+#include "srb_knot.hpp"
 #include "sweep.hpp"
 
 using namespace hs;
@@ -53,6 +54,12 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, in
     const PhaseDev& P = ph[pi];
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
     const size_t slot = (size_t)b * nslots + s;
+    if (P.model == HSDDP_MODEL_SRB) {   // reduced-model tail of the MHPC horizon: a few hundred flops per knot, reuses the whole-body LDS block
+        SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
+        if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
+        else srb_rollout_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b, eps, so, slot);
+        return;
+    }
     if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
     else wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
 }
@@ -64,6 +71,11 @@ __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, 
     __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
     const PhaseDev& P = ph[pi];
+    if (P.model == HSDDP_MODEL_SRB) {
+        SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
+        if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
+        return;
+    }
     if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active);
     else wb_lq_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
 }
@@ -333,7 +345,8 @@ void hsddp_destroy(hsddp_handle_t* h) {
 int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
     if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
     for (int i = 0; i < n_phases; i++) {
-        if (phases[i].model != HSDDP_MODEL_WB) { fprintf(stderr, "[hsddp_hip] phase %d: only the whole-body model runs on the HIP backend in this build\n", i); return HSDDP_ENOTSUP; }
+        if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB) { fprintf(stderr, "[hsddp_hip] phase %d: model %d (HKD) does not run on the HIP backend in this build\n", i, phases[i].model); return HSDDP_ENOTSUP; }
+        if (i > 0 && phases[i].model == HSDDP_MODEL_WB && phases[i - 1].model != HSDDP_MODEL_WB) { fprintf(stderr, "[hsddp_hip] phase %d: no reset map from a reduced model back to the whole-body model (MHPCReset.cpp has none either)\n", i); return HSDDP_ENOTSUP; }
         if (!phases[i].shooting) { fprintf(stderr, "[hsddp_hip] single-shooting phases are not supported (knot-parallel multiple shooting only)\n"); return HSDDP_ENOTSUP; }
         if (phases[i].horizon <= 0) return HSDDP_EINVAL;
     }
@@ -362,7 +375,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     if (!rc) rc |= dalloc(h, &h->d_ph, n_phases);
     if (!rc) rc |= dalloc(h, &h->d_slot_phase, sp.size()); if (!rc) rc |= dalloc(h, &h->d_slot_k, sk.size());
     if (!rc) rc |= dalloc(h, &h->d_fail, B); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
-    if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * 36);
+    if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n);
     if (!rc) rc |= dalloc(h, &h->sa.cost, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * sp.size());
     if (!rc) rc |= dalloc(h, &h->sa.ming, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * sp.size());
     if (rc) { hsddp_destroy(h); return rc; }
@@ -377,14 +390,14 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
 int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) {
     if (!h || !x0) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
-    HIPCK(hipMemcpy(h->d_x0, x0, (size_t)h->batch * 36 * 8, hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(h->d_x0, x0, (size_t)h->batch * h->ph[0].n * 8, hipMemcpyHostToDevice));
     return HSDDP_OK;
 }
 
 int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per_problem) {
     if (!h || phase < 0 || phase >= h->nph) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
-    PhaseDev& P = h->ph[phase]; const size_t sx = (size_t)(P.h + 1) * 36, su = (size_t)P.h * 12, B = h->batch;
+    PhaseDev& P = h->ph[phase]; const size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m, B = h->batch;
     if (Xbar) {
         HIPCK(hipMemcpy(P.Xbar, Xbar, (per_problem ? B : 1) * sx * 8, hipMemcpyHostToDevice));
         if (!per_problem) dev_replicate(P.Xbar, sx * 8, B);
@@ -395,7 +408,7 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
         if (!per_problem) dev_replicate(P.Ubar, su * 8, B);
         HIPCK(hipMemcpy(P.U, P.Ubar, B * su * 8, hipMemcpyDeviceToDevice));
     }
-    HIPCK(hipMemset(P.K, 0, B * P.h * 432 * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
+    HIPCK(hipMemset(P.K, 0, B * P.h * P.m * P.n * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
     return HSDDP_OK;
 }
 

@@ -177,23 +177,29 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     if (j0 < js) for (int j = j0; j < cols; j += js) dst[i + rows * j] = src[i + lds_ * j];
 }
 
-// ---- prefetch of one knot's record (backward sweep): 20 rounds of 256 elements, each round inside ONE array ----
-//   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 C | 16 D | 17 luu | 18 lyy | 19 [lx(36) lu(12) ly(12) Defect[k+1](36)]
+// ---- prefetch of one knot's record (backward sweep): RL::rounds rounds of 256 elements, each inside ONE sub-array,
+//      plus one round for the vectors [lx(N) lu(M) ly(PY) Defect[k+1](N)]
 #define SW_RICCATI_FETCH(kk_, k_) { \
-    const double* rec_ = P.rec + (kk_) * (size_t)REC_SIZE + tid; \
-    _Pragma("unroll") for (int r = 0; r < 19; r++) PRE(r) = rec_[NT * r];     /* sub-arrays start at multiples of 256: one base, constant offsets */ \
-    PRE(19) = (tid < N + M + PY) ? rec_[REC_LX] : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
+    const double* rec_ = P.rec + (kk_) * (size_t)RL::size + tid; \
+    _Pragma("unroll") for (int r = 0; r < RL::rounds; r++) PRE(r) = rec_[NT * r];     /* one base pointer, constant offsets */ \
+    PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
 #define SW_RICCATI_COMMIT() { \
-    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(6 + r); } } \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; if (e < N * M) S.B[(e % N) + LDN * (e / N)] = PRE(12 + r); if (e < PY * N) S.C[(e % PY) + LDM * (e / PY)] = PRE(14 + r); } \
-    if (tid < PY * M) S.D[(tid % PY) + LDM * (tid / PY)] = PRE(16); if (tid < M * M) S.Quu[(tid % M) + LDM * (tid / M)] = PRE(17); if (tid < PY * PY) S.lyy[(tid % PY) + LDM * (tid / PY)] = PRE(18); \
-    if (tid < N) S.Qx[tid] = PRE(19); else if (tid < N + M) S.Qu[tid - N] = PRE(19); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(19); else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(19); }
+    constexpr int PYd = PY > 0 ? PY : 1; \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) S.B[(e % N) + LDN * (e / N)] = PRE(2 * RL::rA + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rC; r++) { const int e = tid + NT * r; if (e < PY * N) S.C[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rD; r++) { const int e = tid + NT * r; if (e < PY * M) S.D[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + RL::rC + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) S.Quu[(e % M) + LDM * (e / M)] = PRE(2 * RL::rA + RL::rB + RL::rC + RL::rD + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLyy; r++) { const int e = tid + NT * r; if (e < PY * PY) S.lyy[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + RL::rC + RL::rD + RL::rLuu + r); } \
+    if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
+    else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
-    static_assert(REC_LXX == 6 * NT && REC_B == 12 * NT && REC_C == 14 * NT && REC_D == 16 * NT && REC_LUU == 17 * NT && REC_LYY == 18 * NT && REC_LX == 19 * NT && REC_LU == REC_LX + N && REC_LY == REC_LU + M, "record layout");
-    static_assert(NT == 256 && N % 3 == 0 && M % 3 == 0 && PY % 3 == 0 && N % 2 == 0 && M % 2 == 0, "tile shapes");
+    using RL = RecLayout<N, M, PY>;
+    static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && M <= SW_M && N <= SW_N && PY <= SW_P, "sweep limits");
+    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
     const int h = P.h;
     SW_PRE_DECL
     // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327); prefetch knot h-1
@@ -206,36 +212,39 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         SW_STAMP0()
         HS_PHASE_L(NT, SW_RICCATI_COMMIT() if (k > 0) SW_RICCATI_FETCH(kk - 1, k - 1))
         SW_STAMP(0)
-        // phase 1 (matrix cores, 30 MFMAs per wave): HA = H A (9 tiles: waves 0-2) ; HB = H B (3 tiles: wave 3) ;
-        // lC = lyy C (3 tiles: waves 1-3) ; lD = lyy D (wave 0) ; Gnext = G + H Defect[k+1]
+        // phase 1 (matrix cores): HA = H A (TN x TN tiles) ; HB = H B (TN x TM) ; lC = lyy C (TP x TN) ; lD = lyy D (TP x TM), dealt
+        // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            if (w < 3) { for (int t = 0; t < 3; t++) { const int tile = 3 * w + t; mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (tile % 3), 16 * (tile / 3), N, N, S.H, LDN, S.A, LDN); } }
-            else { for (int t = 0; t < 3; t++) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * t, 0, N, M, S.H, LDN, S.B, LDN); }
-            if (PY > 0) {
-                if (w == 0) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 0, 0, PY, M, S.lyy, LDM, S.D, LDM);
-                else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 0, 16 * (w - 1), PY, N, S.lyy, LDM, S.C, LDM);
+            constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
+            for (int t = w; t < t4; t += 4) {
+                if (t < t1) mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN);
+                else if (t < t2) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN);
+                else if (t < t3) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 16 * ((t - t2) % (TP > 0 ? TP : 1)), 16 * ((t - t2) / (TP > 0 ? TP : 1)), PY, N, S.lyy, LDM, S.C, LDM);
+                else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 16 * ((t - t3) % (TP > 0 ? TP : 1)), 16 * ((t - t3) / (TP > 0 ? TP : 1)), PY, M, S.lyy, LDM, S.D, LDM);
             }
             if (tid < N) { double s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
         })
         SW_STAMP(1)
-        // phase 2: Qxx += A^T HA + C^T lC (9 tiles: waves 0-2) ; Qux = B^T HA + D^T lC (3 tiles) and Quu += B^T HB + D^T lD (wave 3) ;
+        // phase 2: Qxx += A^T HA + C^T lC (TN x TN) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            if (w < 3) {
-                for (int t = 0; t < 3; t++) {
-                    const int tile = 3 * w + t, i0 = 16 * (tile % 3), j0 = 16 * (tile / 3);
+            constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
+            for (int t = w; t < t3; t += 4) {
+                if (t < t1) {
+                    const int i0 = 16 * (t % TN), j0 = 16 * (t / TN);
                     mfma_tile<true, N>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.A, LDN, S.HA, LDN);
                     if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.C, LDM, S.lC, LDM);
+                } else if (t < t2) {
+                    const int i0 = 16 * ((t - t1) % TM), j0 = 16 * ((t - t1) / TM);
+                    mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, i0, j0, M, N, S.B, LDN, S.HA, LDN);
+                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, i0, j0, M, N, S.D, LDM, S.lC, LDM);
+                } else {
+                    const int i0 = 16 * ((t - t2) % TM), j0 = 16 * ((t - t2) / TM);
+                    mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.B, LDN, S.HB, LDN);
+                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.D, LDM, S.lD, LDM);
                 }
-            } else {
-                for (int t = 0; t < 3; t++) {
-                    mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, 0, 16 * t, M, N, S.B, LDN, S.HA, LDN);
-                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, 0, 16 * t, M, N, S.D, LDM, S.lC, LDM);
-                }
-                mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, 0, 0, M, M, S.B, LDN, S.HB, LDN);
-                if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, 0, 0, M, M, S.D, LDM, S.lD, LDM);
             }
             if (tid < N) {
                 double s = 0;
@@ -275,7 +284,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
-              for (int tile = w; tile < 9; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % 3), 16 * (tile / 3), N, N, S.Qux, LDM, S.K, LDM); }
+              for (int tile = w; tile < TN * TN; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % TN), 16 * (tile / TN), N, N, S.Qux, LDM, S.K, LDM); }
             if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
             else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
@@ -291,93 +300,103 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
     return true;
 }
 
-// full multi-phase backward sweep of problem b; returns success, writes dV into S.dV1/dV2.  All phases N/M/PY.
-template <int NT, int N, int M, int PY>
-HD bool riccati_sweep_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
+// full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, SRB 12/12/0);
+// returns success, writes dV into S.dV1/dV2
+template <int NT>
+HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
     HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
         const PhaseDev& P = ph[i];
+        const int n = P.n;
         if (i == nph - 1) {
-            HS_PHASE(NT, for (int e = tid; e < LDN * N; e += NT) S.H[e] = 0.0; if (tid < N) S.G[tid] = 0.0;)
-        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = N x N here  (MultiPhaseDDP.cpp:196-201)
-            HS_PHASE(NT, ld_mat<NT>(tid, S.A, LDN, P.Px + (size_t)b * N * N, N, N);)
+            HS_PHASE(NT, for (int e = tid; e < LDN * n; e += NT) S.H[e] = 0.0; if (tid < n) S.G[tid] = 0.0;)
+        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = nn x n  (MultiPhaseDDP.cpp:196-201); once per phase boundary
+            const int nn = P.next_n;
+            HS_PHASE(NT, ld_mat<NT>(tid, S.A, LDN, P.Px + (size_t)b * nn * n, nn, n);)
             HS_PHASE(NT,
-                if (tid < (N / 3) * (N / 3)) mm_tile<false, 3, 3, N>(tid, N / 3, S.HA, LDN, S.H, LDN, S.A, LDN, false, 1.0);
-                else if (tid >= NT - N) { const int i2 = tid - (NT - N); double s = 0; for (int t = 0; t < N; t++) s += CM(S.A, t, i2, LDN) * S.G[t]; S.Gn[i2] = s; })
+                for (int e = tid; e < nn * n; e += NT) { const int r = e % nn, c = e / nn; double s = 0; for (int t = 0; t < nn; t++) s += CM(S.H, r, t, LDN) * CM(S.A, t, c, LDN); CM(S.HA, r, c, LDN) = s; }
+                if (tid >= NT - n) { const int i2 = tid - (NT - n); double s = 0; for (int t = 0; t < nn; t++) s += CM(S.A, t, i2, LDN) * S.G[t]; S.Gn[i2] = s; })
             HS_PHASE(NT,
-                if (tid < (N / 3) * (N / 3)) mm_tile<true, 3, 3, N>(tid, N / 3, S.H, LDN, S.A, LDN, S.HA, LDN, false, 1.0);
-                else if (tid >= NT - N) S.G[tid - (NT - N)] = S.Gn[tid - (NT - N)];)
+                for (int e = tid; e < n * n; e += NT) { const int r = e % n, c = e / n; double s = 0; for (int t = 0; t < nn; t++) s += CM(S.A, t, r, LDN) * CM(S.HA, t, c, LDN); CM(S.H, r, c, LDN) = s; }
+                if (tid >= NT - n) S.G[tid - (NT - n)] = S.Gn[tid - (NT - n)];)
         }
-        if (!riccati_phase<NT, N, M, PY>(S, P, b, reg)) return false;
+        const bool ok = (P.n == 36) ? riccati_phase<NT, 36, 12, 12>(S, P, b, reg) : riccati_phase<NT, 12, 12, 0>(S, P, b, reg);
+        if (!ok) return false;
     }
     return true;
 }
-template <int NT>
-HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) { return riccati_sweep_t<NT, SW_N, SW_M, SW_P>(S, ph, nph, b, reg); }
 
-// ---- linear rollout: forward over phases/knots; next knot prefetched into 18 registers per thread (dense ld = rows) ----
-//   rounds 0-5 A | 6-11 lxx | 12-13 B | 14-15 K | 16 luu | 17 [lx(36) lu(12) dU(12) Defect[k+1](36)]
+// ---- linear rollout: forward over phases/knots; next knot prefetched into registers (dense ld = rows layouts) ----
+//   rounds: A (rA) | lxx (rA) | B (rB) | K (rB) | luu (rLuu) | [lx(N) lu(M) dU(M) Defect[k+1](N)]
 #define SW_LIN_FETCH(kk_, k_) { \
-    const double* rec_ = P.rec + (kk_) * (size_t)REC_SIZE + tid; \
-    _Pragma("unroll") for (int r = 0; r < 6; r++) { PRE(r) = rec_[REC_A + NT * r]; PRE(6 + r) = rec_[REC_LXX + NT * r]; } \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; PRE(12 + r) = rec_[REC_B + NT * r]; PRE(14 + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
-    PRE(16) = rec_[REC_LUU]; \
-    PRE(17) = (tid < N + M) ? rec_[REC_LX] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
+    const double* rec_ = P.rec + (kk_) * (size_t)RL::size + tid; \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { PRE(r) = rec_[RL::oA + NT * r]; PRE(RL::rA + r) = rec_[RL::oLxx + NT * r]; } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(2 * RL::rA + 2 * RL::rB + r) = rec_[RL::oLuu + NT * r]; \
+    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
             : (tid < 2 * N + 2 * M) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
 #define SW_LIN_COMMIT() { \
-    _Pragma("unroll") for (int r = 0; r < 6; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[e] = PRE(r); S.Qxx[e] = PRE(6 + r); } } \
-    _Pragma("unroll") for (int r = 0; r < 2; r++) { const int e = tid + NT * r; if (e < N * M) { S.B[e] = PRE(12 + r); S.K[e] = PRE(14 + r); } } \
-    if (tid < M * M) S.Quu[tid] = PRE(16); \
-    if (tid < N) S.Qx[tid] = PRE(17); else if (tid < N + M) S.Qu[tid - N] = PRE(17); else if (tid < N + 2 * M) S.dU[tid - N - M] = PRE(17); else if (tid < 2 * N + 2 * M) S.def[tid - N - 2 * M] = PRE(17); }
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[e] = PRE(r); S.Qxx[e] = PRE(RL::rA + r); } } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) { S.B[e] = PRE(2 * RL::rA + r); S.K[e] = PRE(2 * RL::rA + RL::rB + r); } } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) S.Quu[e] = PRE(2 * RL::rA + 2 * RL::rB + r); } \
+    { const double v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
+      if (tid < N) S.Qx[tid] = v_; else if (tid < N + M) S.Qu[tid - N] = v_; else if (tid < N + 2 * M) S.dU[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) S.def[tid - N - 2 * M] = v_; } }
 
-template <int NT, int N, int M>
-HD void linear_rollout_t(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
+// one phase of the linear rollout; on entry S.dxn holds dx_init (Px * dX_end of the previous phase, or 0)
+template <int NT, int N, int M, int PY>
+HD void linear_phase(SweepLds& S, const PhaseDev& P, int b, double eps) {
+    using RL = RecLayout<N, M, PY>;
+    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE, "prefetch registers");
+    const int h = P.h;
     SW_PRE_DECL
-    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; } if (tid < N) S.dxn[tid] = 0.0;)
+    // dX[0] = dx_init + eps * Defect[0]
+    HS_PHASE(NT, if (tid < N) { double v = S.dxn[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
+             SW_LIN_FETCH((size_t)b * h, 0))
+    for (int k = 0; k < h; k++) {
+        const size_t kk = (size_t)b * h + k;
+        HS_PHASE_L(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
+        HS_PHASE_L(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
+        HS_PHASE_L(NT,
+            if (tid < N) {
+                double s = 0, q = 0;
+                _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
+                double s2 = 0;
+                _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(S.B, tid, j, N) * S.du[j];
+                const double v = s + s2 + eps * S.def[tid];
+                S.dxn[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
+                S.red[tid] = S.dx[tid] * q;            // dx^T lxx dx contributions
+                S.red[64 + tid] = S.Qx[tid] * S.dx[tid];
+            } else if (tid >= 128 && tid < 128 + M) {
+                const int a = tid - 128; double q = 0;
+                _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(S.Quu, a, j, M) * S.du[j];
+                S.red[tid] = S.du[a] * q; S.red[64 + tid] = S.Qu[a] * S.du[a];
+            })
+        HS_PHASE_L(NT, if (tid == 0) {
+            double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+            for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
+            for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
+            S.dV1 += a1 + b1; S.dV2 += a2; S.dV2 += b2;      // (+ du^T lux dx with lux == 0)
+        } if (tid >= 64 && tid < 64 + N) S.dx[tid - 64] = S.dxn[tid - 64];)
+    }
+    // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx
+    HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
+    HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * N + tid] * S.dx[tid]; })
+    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } S.dV1 += a1; S.dV2 += a2; })
+}
+
+// linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.dV1/dV2.
+template <int NT>
+HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
+    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; } if (tid < SW_N) S.dxn[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
         const PhaseDev& P = ph[i];
-        const int h = P.h;
-        if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); S.dx holds prev terminal dX
-            const PhaseDev& Pp = ph[i - 1];
-            HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.A[e] = Pp.Px[(size_t)b * N * N + e];)
-            HS_PHASE(NT, if (tid < N) { double s = 0; for (int t = 0; t < N; t++) s += CM(S.A, tid, t, N) * S.dx[t]; S.dxn[tid] = s; })
+        if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); S.dx holds the previous phase's terminal dX
+            const PhaseDev& Pp = ph[i - 1]; const int np = Pp.n, n = P.n;
+            HS_PHASE(NT, for (int e = tid; e < n * np; e += NT) S.A[e] = Pp.Px[(size_t)b * n * np + e];)
+            HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += CM(S.A, tid, t, n) * S.dx[t]; S.dxn[tid] = s; })
         }
-        // dX[0] = dx_init + eps * Defect[0]
-        HS_PHASE(NT, if (tid < N) { double v = S.dxn[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
-                 SW_LIN_FETCH((size_t)b * h, 0))
-        for (int k = 0; k < h; k++) {
-            const size_t kk = (size_t)b * h + k;
-            HS_PHASE_L(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
-            HS_PHASE_L(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
-            HS_PHASE_L(NT,
-                if (tid < N) {
-                    double s = 0, q = 0;
-                    _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
-                    double s2 = 0;
-                    _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(S.B, tid, j, N) * S.du[j];
-                    const double v = s + s2 + eps * S.def[tid];
-                    S.dxn[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
-                    S.red[tid] = S.dx[tid] * q;            // dx^T lxx dx contributions
-                    S.red[64 + tid] = S.Qx[tid] * S.dx[tid];
-                } else if (tid >= 128 && tid < 128 + M) {
-                    const int a = tid - 128; double q = 0;
-                    _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(S.Quu, a, j, M) * S.du[j];
-                    S.red[tid] = S.du[a] * q; S.red[64 + tid] = S.Qu[a] * S.du[a];
-                })
-            HS_PHASE_L(NT, if (tid == 0) {
-                double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
-                for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
-                for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
-                S.dV1 += a1 + b1; S.dV2 += a2; S.dV2 += b2;      // (+ du^T lux dx with lux == 0)
-            } if (tid >= 64 && tid < 64 + N) S.dx[tid - 64] = S.dxn[tid - 64];)
-        }
-        // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx
-        HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
-        HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * N + tid] * S.dx[tid]; })
-        HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } S.dV1 += a1; S.dV2 += a2; })
+        if (P.n == 36) linear_phase<NT, 36, 12, 12>(S, P, b, eps); else linear_phase<NT, 12, 12, 0>(S, P, b, eps);
     }
 }
-template <int NT>
-HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) { linear_rollout_t<NT, SW_N, SW_M>(S, ph, nph, b, eps); }
 
 }  // namespace hs

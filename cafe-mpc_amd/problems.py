@@ -204,3 +204,69 @@ def srb_phase(horizon, dt, t_offset, refs):
         bufs[name] = a; setattr(d, name, a.ctypes.data_as(DP))
     rc = np.ascontiguousarray(refs["ref_contact"], dtype=np.int32); bufs["ref_contact"] = rc; d.ref_contact = rc.ctypes.data_as(IP)
     return {"desc": d, "bufs": bufs, "Xbar": bufs["xr"].copy(), "Ubar": np.zeros((horizon, 12))}
+
+
+def mhpc_problem(wb_schedule=((1, 1, 1, 1), (0, 1, 1, 0)), wb_horizons=(25, 25), srb_schedule=((1, 0, 0, 1), (0, 1, 1, 0)),
+                 srb_horizons=(5, 5), dt_wb=0.01, dt_srb=0.05, vx=0.5, swing_height=0.06, ubar_mode="gravity_comp"):
+    """The MHPC horizon proper (MHPCProblem.cpp:373-521, mhpc_config.yaml): whole-body phases followed by a
+    single-rigid-body tail at a coarser time step; the last WB phase resets into the SRB state through the
+    impact map and the state projection (MHPCReset.cpp:4-52).  Synthetic trot references as in wb_trot_problem."""
+    sched = list(wb_schedule) + list(srb_schedule)
+    hs_ = list(wb_horizons) + list(srb_horizons)
+    dts = [dt_wb] * len(wb_schedule) + [dt_srb] * len(srb_schedule)
+    nph, nwb = len(sched), len(wb_schedule)
+    t0 = np.concatenate([[0.0], np.cumsum([h * d for h, d in zip(hs_, dts)])])
+    nominal_feet = wb_foot_positions(wb_nominal_state()[:18]); nominal_feet[:, 2] = 0.0
+
+    def foothold(i, f):
+        i = min(max(i, 0), nph - 1)
+        return nominal_feet[f] + np.array([vx * 0.5 * (t0[i] + t0[i + 1]), 0, 0])
+
+    phases = []
+    for i in range(nph):
+        h, dt = hs_[i], dts[i]
+        nxt = sched[i + 1] if i + 1 < nph else sched[i]
+        n = 36 if i < nwb else 12
+        xr = np.zeros((h + 1, n)); fp = np.zeros((h + 1, 12)); fv = np.zeros((h + 1, 12)); rc = np.zeros((h + 1, 4), dtype=np.int32)
+        grf = np.zeros((h + 1, 12)); bp = np.zeros((h + 1, 3))
+        for k in range(h + 1):
+            t = t0[i] + k * dt
+            bp[k] = [vx * t, 0.0, Z_NOM]
+            if i < nwb:
+                xr[k, 0] = vx * t; xr[k, 2] = Z_NOM; xr[k, 6:18] = QJ_NOM; xr[k, 18] = vx
+            else:
+                xr[k, 0] = vx * t; xr[k, 2] = Z_NOM; xr[k, 6] = vx
+            c = sched[i] if k < h else nxt
+            rc[k] = c
+            nc = max(1, int(np.sum(c)))
+            for f in range(4):
+                if sched[i][f]:
+                    fp[k, 3 * f:3 * f + 3] = foothold(i, f)
+                else:
+                    p0, p1 = foothold(i - 1, f), foothold(i + 1, f)
+                    if i == 0:
+                        p0 = foothold(0, f) - np.array([vx * h * dt, 0, 0])
+                    if i == nph - 1:
+                        p1 = foothold(i, f) + np.array([vx * h * dt, 0, 0])
+                    s = k / h
+                    fp[k, 3 * f:3 * f + 3] = p0 + (p1 - p0) * s + np.array([0, 0, swing_height * np.sin(np.pi * s)])
+                    fv[k, 3 * f:3 * f + 3] = (p1 - p0) / (h * dt) + np.array([0, 0, swing_height * np.pi / (h * dt) * np.cos(np.pi * s)])
+                if c[f]:
+                    grf[k, 3 * f + 2] = MASS_WB * 9.81 / nc
+        if i < nwb:
+            refs = dict(xr=xr, ur=np.zeros((h + 1, 12)), yr=grf, foot_pos=fp, foot_vel=fv, body_pos=bp, ref_contact=rc)
+            phases.append(wb_phase(h, dt, t0[i], sched[i], nxt, refs, next_model=MODEL_WB if i + 1 < nwb else MODEL_SRB, ubar_mode=ubar_mode))
+        else:
+            # SRB knots take their contact set from the reference (SRBM.h:43-60): stance feet of THIS phase at every knot
+            rc[:] = np.array(sched[i], dtype=np.int32)
+            nc = max(1, int(np.sum(sched[i])))
+            grf[:] = 0.0
+            for f in range(4):
+                if sched[i][f]:
+                    grf[:, 3 * f + 2] = 8.912 * 9.81 / nc
+            refs = dict(xr=xr, ur=grf, foot_pos=fp, foot_vel=fv, body_pos=bp, ref_contact=rc)
+            ph = srb_phase(h, dt, t0[i], refs)
+            if ubar_mode == "gravity_comp":
+                ph["Ubar"] = grf[:h].copy()
+            phases.append(ph)
+    return phases

@@ -13,6 +13,7 @@
 #include "hs_types.hpp"
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
+#include "srb_knot.hpp"
 #include "sweep.hpp"
 
 using namespace hs;
@@ -40,36 +41,40 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI; h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
     h->ph.resize(n_phases); HostMem mem{h};
     for (int i = 0; i < n_phases; i++) {
-        if (phases[i].model != HSDDP_MODEL_WB) return HSDDP_ENOTSUP;
+        if (phases[i].model == HSDDP_MODEL_HKD || (i > 0 && phases[i].model == HSDDP_MODEL_WB && phases[i - 1].model != HSDDP_MODEL_WB)) return HSDDP_ENOTSUP;
         int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, batch, h->ph[i], (int)h->sp.size());
         if (rc) return rc;
         for (int k = 0; k <= phases[i].horizon; k++) { h->sp.push_back(i); h->sk.push_back(k); }
     }
     h->nslots = h->sp.size(); size_t t = (size_t)batch * h->nslots;
-    h->cost.assign(t, 0); h->dsq.assign(t, 0); h->ming.assign(t, 0); h->maxh.assign(t, 0); h->x0.assign((size_t)batch * 36, 0);
+    h->cost.assign(t, 0); h->dsq.assign(t, 0); h->ming.assign(t, 0); h->maxh.assign(t, 0); h->x0.assign((size_t)batch * h->ph[0].n, 0);
     h->dV1.assign(batch, 0); h->dV2.assign(batch, 0); h->feas.assign(batch, 0); h->acost.assign(batch, 0); h->fail.assign(batch, 0);
     *out = h; return 0;
 }
 void hsddp_destroy(hsddp_handle_t* h) { if (!h) return; for (void* p : h->allocs) free(p); delete h; }
 int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) { memcpy(h->x0.data(), x0, h->x0.size() * 8); return 0; }
 int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per) {
-    PhaseDev& P = h->ph[phase]; size_t sx = (size_t)(P.h + 1) * 36, su = (size_t)P.h * 12;
+    PhaseDev& P = h->ph[phase]; size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m;
     for (size_t b = 0; b < (size_t)h->batch; b++) {
         if (Xbar) { memcpy(P.Xbar + b * sx, Xbar + (per ? b * sx : 0), sx * 8); memcpy(P.X + b * sx, Xbar + (per ? b * sx : 0), sx * 8); }
         if (Ubar) { memcpy(P.Ubar + b * su, Ubar + (per ? b * su : 0), su * 8); memcpy(P.U + b * su, Ubar + (per ? b * su : 0), su * 8); }
     }
-    memset(P.K, 0, (size_t)h->batch * P.h * 432 * 8); memset(P.dU, 0, h->batch * su * 8); memset(P.dX, 0, h->batch * sx * 8);
+    memset(P.K, 0, (size_t)h->batch * P.h * P.m * P.n * 8); memset(P.dU, 0, h->batch * su * 8); memset(P.dX, 0, h->batch * sx * 8);
     return 0;
 }
 static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
 int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
     OptDev o = to_dev(*opt); SlotOut so{h->cost.data(), h->dsq.data(), h->ming.data(), h->maxh.data()};
-    static WbCore L;
+    static WbCore L; static SrbLds Ls;
     for (int b = 0; b < h->batch; b++) {
         h->fail[b] = 0;
         for (int s = 0; s < h->nslots; s++) {
             int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi]; size_t slot = (size_t)b * h->nslots + s;
-            if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+            const PhaseDev* Pn = pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr;
+            if (P.model == HSDDP_MODEL_SRB) {
+                if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+                else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot);
+            } else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
             else wb_rollout_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, eps, o.AL_active, so, slot);
         }
         double c = 0, d = 0; for (int s = 0; s < h->nslots; s++) { c += h->cost[(size_t)b * h->nslots + s]; d += h->dsq[(size_t)b * h->nslots + s]; }
@@ -79,10 +84,11 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
 }
 int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }
 int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
-    OptDev o = to_dev(*opt); static WbLqLds L;
+    OptDev o = to_dev(*opt); static WbLqLds L; static SrbLds Ls;
     for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
         int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
-        if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
+        if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
+        else if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
         else wb_lq_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
     }
     return 0;
@@ -98,7 +104,7 @@ int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t*) {
     return 0;
 }
 int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {
-    for (auto& P : h->ph) { size_t nx = (size_t)h->batch * (P.h + 1) * 36, nu = (size_t)h->batch * P.h * 12; memcpy(P.Xbar, P.X, nx * 8); memcpy(P.Defect_bar, P.Defect, nx * 8); memcpy(P.Ubar, P.U, nu * 8); }
+    for (auto& P : h->ph) { size_t nx = (size_t)h->batch * (P.h + 1) * P.n, nu = (size_t)h->batch * P.h * P.m; memcpy(P.Xbar, P.X, nx * 8); memcpy(P.Defect_bar, P.Defect, nx * 8); memcpy(P.Ubar, P.U, nu * 8); }
     return 0;
 }
 int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* a, double* b) { memcpy(a, h->dV1.data(), h->batch * 8); memcpy(b, h->dV2.data(), h->batch * 8); return 0; }

@@ -38,10 +38,19 @@ def test_kkt_golden_vectors_gpu(hip_lib):
         assert np.abs(xs[:18] - (1.0 + dt)).max() < 1e-14
 
 
-@pytest.mark.parametrize("which", ["stance", "trot"])
+def _srb_x0(x0):
+    return np.ascontiguousarray(x0[:, list(range(6)) + list(range(18, 24))])     # StateProjection (MHPCReset.h:24-26)
+
+
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only"])
 def test_per_iterate_parity(hip_lib, oracle_lib, which):
-    phases = pkg.problems.wb_stance_problem(horizon=12) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(7, 6, 5, 6))
     x0 = pkg.problems.wb_ensemble_x0(3, 20241222)
+    if which == "mhpc":        # whole-body phases + single-rigid-body tail (state dimension 36 -> 12 across the impact reset)
+        phases = pkg.problems.mhpc_problem(wb_horizons=(7, 6), srb_horizons=(5, 4))
+    elif which == "srb_only":
+        phases = pkg.problems.mhpc_problem(wb_schedule=(), wb_horizons=(), srb_horizons=(6, 5)); x0 = _srb_x0(x0)
+    else:
+        phases = pkg.problems.wb_stance_problem(horizon=12) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(7, 6, 5, 6))
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
     pc.run_steps(pkg, so, sg, phases, pkg.mhpc_ddp_setting(), n_iter=3)
 
@@ -55,6 +64,17 @@ def test_full_solve_parity_trot(hip_lib, oracle_lib):
     so.solve(opt); sg.solve(opt)
     pc.compare_solve(so, sg, len(phases))
     assert (sg.info_arrays()["n_iters"] > 2).all()
+
+
+def test_full_solve_parity_mhpc(hip_lib, oracle_lib):
+    """The MHPC horizon of mhpc_config.yaml in shape: whole-body plan (dt 0.01) + SRB tail (dt 0.05), full solve."""
+    phases = pkg.problems.mhpc_problem(wb_horizons=(25, 25), srb_horizons=(5, 5))
+    x0 = pkg.problems.wb_ensemble_x0(4, 20241224)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
+    assert (sg.info_arrays()["n_iters"] >= 2).all()
 
 
 def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):

@@ -5,6 +5,7 @@ import ctypes
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import pkg, ROOT
@@ -18,9 +19,15 @@ def emu_lib():
     return pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu.so")))
 
 
-@pytest.mark.parametrize("which", ["stance", "trot"])
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only"])
 def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
-    phases = pkg.problems.wb_stance_problem(horizon=5) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+    if which == "mhpc":    # whole-body phases + single-rigid-body tail: mixed state dimension across the phase boundary
+        phases = pkg.problems.mhpc_problem(wb_horizons=(4, 3), srb_horizons=(3, 2))
+    else:
+        phases = pkg.problems.wb_stance_problem(horizon=5) if which == "stance" else pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
     x0 = pkg.problems.wb_ensemble_x0(2, 20241222)
+    if which == "srb_only":
+        phases = pkg.problems.mhpc_problem(wb_schedule=(), wb_horizons=(), srb_horizons=(4, 3))
+        x0 = np.ascontiguousarray(x0[:, list(range(6)) + list(range(18, 24))])
     so, se = pc.make_pair(pkg, oracle_lib, emu_lib, phases, x0)
     pc.run_steps(pkg, so, se, phases, pkg.mhpc_ddp_setting(), n_iter=2)
