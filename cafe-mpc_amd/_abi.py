@@ -66,6 +66,7 @@ class PhaseDesc(C.Structure):
                 ("torque_limit", C.c_double), ("joint_lb", C.c_double * 3), ("joint_ub", C.c_double * 3),
                 ("h_min", C.c_double), ("mu", C.c_double),
                 ("reb_torque", Reb), ("reb_joint", Reb), ("reb_minheight", Reb), ("reb_grf", Reb),
+                ("c_jointspeed", C.c_int), ("jointspeed_lb", C.c_double), ("jointspeed_ub", C.c_double), ("reb_jointspeed", Reb),
                 ("c_touchdown", C.c_int), ("ground_height", C.c_double), ("al_td", Al),
                 ("xr", DP), ("ur", DP), ("yr", DP), ("foot_pos", DP), ("foot_vel", DP), ("body_pos", DP),
                 ("ref_contact", IP)]

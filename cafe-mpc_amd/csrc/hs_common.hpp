@@ -11,6 +11,7 @@
 
 #ifdef HS_HOST_EMU
 #define HD inline
+#define HDH inline
 #define HS_SHARED static thread_local
 #define HS_PHASE(NT, ...) { for (int tid = 0; tid < (NT); ++tid) { __VA_ARGS__ } }
 // wave-level phase: only the first 64 threads of the workgroup run it, ordered by a wave barrier (no s_barrier)
@@ -19,6 +20,7 @@
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
+#define HDH __host__ __device__ inline
 #define HS_SHARED __shared__
 #define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); if (tid < (NT)) { __VA_ARGS__ } } __syncthreads(); }
 // wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program

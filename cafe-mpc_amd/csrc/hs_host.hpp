@@ -10,13 +10,6 @@
 
 namespace hs {
 
-inline int constraint_group(const PhaseDev& P, int c) {
-    if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) return 0;
-    if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) return 1;
-    if (P.go_height >= 0 && c == P.go_height) return 2;
-    return 3;
-}
-
 // Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes);
 //             void replicate(void* base, size_t bytes_one, size_t count): copies record 0 into records 1..count-1
 template <class Mem>
@@ -38,12 +31,14 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     P.c_torque = d.c_torque; P.c_joint = d.c_joint; P.c_minheight = d.c_minheight; P.c_grf = d.c_grf; P.c_touchdown = d.c_touchdown;
     P.torque_limit = d.torque_limit; std::memcpy(P.joint_lb, d.joint_lb, 24); std::memcpy(P.joint_ub, d.joint_ub, 24);
     P.h_min = d.h_min; P.mu = d.mu; P.ground_height = d.ground_height;
-    const hsddp_reb_t* rb[4] = {&d.reb_torque, &d.reb_joint, &d.reb_minheight, &d.reb_grf};
-    for (int g = 0; g < 4; g++) { P.reb_init[g][0] = rb[g]->delta; P.reb_init[g][1] = rb[g]->delta_min; P.reb_init[g][2] = rb[g]->eps; }
+    P.c_jspeed = d.c_jointspeed; P.jspeed_lb = d.jointspeed_lb; P.jspeed_ub = d.jointspeed_ub;
+    const hsddp_reb_t* rb[5] = {&d.reb_torque, &d.reb_joint, &d.reb_minheight, &d.reb_grf, &d.reb_jointspeed};
+    for (int g = 0; g < 5; g++) { P.reb_init[g][0] = rb[g]->delta; P.reb_init[g][1] = rb[g]->delta_min; P.reb_init[g][2] = rb[g]->eps; }
     P.al_init[0] = d.al_td.sigma; P.al_init[1] = d.al_td.lambda; P.al_init[2] = d.al_td.sigma_max;
-    int ng = 0; P.go_torque = P.go_joint = P.go_height = P.go_grf = -1;
+    int ng = 0; P.go_torque = P.go_joint = P.go_height = P.go_grf = P.go_jspeed = -1;
     const bool wb = d.model == HSDDP_MODEL_WB;
     if (wb && d.c_torque) { P.go_torque = ng; ng += 24; }
+    if (wb && d.c_jointspeed) { P.go_jspeed = ng; ng += 24; }
     if (wb && d.c_joint) { P.go_joint = ng; ng += 24; }
     if (d.c_minheight) { P.go_height = ng; ng += 1; }
     if (wb && d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }

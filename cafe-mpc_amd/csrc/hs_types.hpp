@@ -4,7 +4,7 @@
 
 namespace hs {
 
-constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 72;
+constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 96;   // MAXG: 24 torque + 24 joint speed + 24 joint + 1 height + 20 GRF
 // LQ record layout (doubles) of one knot for a model with dims (N, M, PY): every sub-array starts at a multiple of 256
 // doubles so that a 256-thread workgroup streams the record in rounds that each lie inside ONE sub-array.
 //   A | lxx | B | C | D | luu | lyy | [lx lu ly]
@@ -26,11 +26,11 @@ struct PhaseDev {
     int contact[4], next_contact[4], td[4], feet[4];
     int nc, n_td, has_impact, next_model, next_n, shooting, is_last;
     double q[MAXN], r[MAXM], qf[MAXN], w_foot_reg[3], w_swing_pos[3], w_swing_vel[3], w_td_vel;
-    int c_torque, c_joint, c_minheight, c_grf, c_touchdown;
-    double torque_limit, joint_lb[3], joint_ub[3], h_min, mu, ground_height;
-    double reb_init[4][3];   // torque, joint, minheight, grf : delta, delta_min, eps
+    int c_torque, c_joint, c_minheight, c_grf, c_touchdown, c_jspeed;
+    double torque_limit, joint_lb[3], joint_ub[3], h_min, mu, ground_height, jspeed_lb, jspeed_ub;
+    double reb_init[5][3];   // torque, joint, minheight, grf, joint speed : delta, delta_min, eps
     double al_init[3];       // sigma, lambda, sigma_max
-    int ng, go_torque, go_joint, go_height, go_grf;   // path-constraint count and group offsets (-1: absent)
+    int ng, go_torque, go_joint, go_height, go_grf, go_jspeed;   // path-constraint count and group offsets (-1: absent)
     int nt;                                           // terminal constraints (touchdown feet)
     int slot0;                                        // first global slot of this phase (slots = h+1 per phase)
     // reference arrays shared by the batch: (h+1) x width
@@ -51,6 +51,25 @@ struct PhaseDev {
     double *g, *delta, *eps;                                           // h x ng
     double *th, *sigma, *lambda;                                       // nt
 };
+
+// ReB parameter group of path constraint c (index into reb_init)
+HDH int constraint_group(const PhaseDev& P, int c) {
+    if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) return 0;
+    if (P.go_jspeed >= 0 && c >= P.go_jspeed && c < P.go_jspeed + 24) return 4;
+    if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) return 1;
+    if (P.go_height >= 0 && c == P.go_height) return 2;
+    return 3;
+}
+// constraint objects of a phase in the order the reference adds them (one `l += dt * ReB_cost` each, SinglePhase.cpp:394-402)
+HD int constraint_objects(const PhaseDev& P, int* offs, int* sz) {
+    int n = 0;
+    if (P.go_torque >= 0) { offs[n] = P.go_torque; sz[n++] = 24; }
+    if (P.go_jspeed >= 0) { offs[n] = P.go_jspeed; sz[n++] = 24; }
+    if (P.go_joint >= 0) { offs[n] = P.go_joint; sz[n++] = 24; }
+    if (P.go_height >= 0) { offs[n] = P.go_height; sz[n++] = 1; }
+    if (P.go_grf >= 0) { offs[n] = P.go_grf; sz[n++] = 5 * P.nc; }
+    return n;
+}
 
 // control flags of the per-problem state machine (MultiPhaseDDP::solve as masks over the batch)
 struct ProbState {

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph, const int* slot
         if (tid == 0) {
             double l = P.lbase[kk];
             if (opt.ReB_active) {
-                int offs[4] = {P.go_torque, P.go_joint, P.go_height, P.go_grf}; int sz[4] = {24, 24, 1, 5 * P.nc};
-                for (int gI = 0; gI < 4; gI++) if (offs[gI] >= 0) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += bar[offs[gI] + i]; l += P.dt * c; }
+                int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz);
+                for (int gI = 0; gI < nobj; gI++) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += bar[offs[gI] + i]; l += P.dt * c; }
             }
             P.l[kk] = l; sa.cost[slot] = l;
         }
@@ -166,7 +166,7 @@ __global__ void k_update_params(const PhaseDev* ph, int nph, OptDev opt, const P
             for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
                 const size_t gi = (size_t)b * tot + i; const int c = (int)(i % P.ng);
                 if (P.g[gi] > -opt.pconstr_thresh) continue;
-                int grp = (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) ? 0 : (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) ? 1 : (P.go_height >= 0 && c == P.go_height) ? 2 : 3;
+                const int grp = constraint_group(P, c);
                 P.eps[gi] *= opt.update_ReB;
                 P.delta[gi] = fmax(P.delta[gi] * opt.update_relax, P.reb_init[grp][1]);
             }

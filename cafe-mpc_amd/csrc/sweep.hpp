@@ -194,6 +194,40 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
     else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
 
+// MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
+// parameter so that every tile's kind and offsets are compile-time constants after unrolling.
+template <int W, int N, int M, int PY>
+HD void sweep_tiles1(SweepLds& S, int lane) {
+    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;
+    constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
+    _Pragma("unroll") for (int t = W; t < t4; t += 4) {
+        if (t < t1) mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN);
+        else if (t < t2) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN);
+        else if (t < t3) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 16 * ((t - t2) % (TP > 0 ? TP : 1)), 16 * ((t - t2) / (TP > 0 ? TP : 1)), PY, N, S.lyy, LDM, S.C, LDM);
+        else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 16 * ((t - t3) % (TP > 0 ? TP : 1)), 16 * ((t - t3) / (TP > 0 ? TP : 1)), PY, M, S.lyy, LDM, S.D, LDM);
+    }
+}
+template <int W, int N, int M, int PY>
+HD void sweep_tiles2(SweepLds& S, int lane) {
+    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
+    constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
+    _Pragma("unroll") for (int t = W; t < t3; t += 4) {
+        if (t < t1) {
+            const int i0 = 16 * (t % TN), j0 = 16 * (t / TN);
+            mfma_tile<true, N>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.A, LDN, S.HA, LDN);
+            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.C, LDM, S.lC, LDM);
+        } else if (t < t2) {
+            const int i0 = 16 * ((t - t1) % TM), j0 = 16 * ((t - t1) / TM);
+            mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, i0, j0, M, N, S.B, LDN, S.HA, LDN);
+            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, i0, j0, M, N, S.D, LDM, S.lC, LDM);
+        } else {
+            const int i0 = 16 * ((t - t2) % TM), j0 = 16 * ((t - t2) / TM);
+            mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.B, LDN, S.HB, LDN);
+            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.D, LDM, S.lD, LDM);
+        }
+    }
+}
+
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
@@ -216,13 +250,8 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
-            for (int t = w; t < t4; t += 4) {
-                if (t < t1) mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN);
-                else if (t < t2) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN);
-                else if (t < t3) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 16 * ((t - t2) % (TP > 0 ? TP : 1)), 16 * ((t - t2) / (TP > 0 ? TP : 1)), PY, N, S.lyy, LDM, S.C, LDM);
-                else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 16 * ((t - t3) % (TP > 0 ? TP : 1)), 16 * ((t - t3) / (TP > 0 ? TP : 1)), PY, M, S.lyy, LDM, S.D, LDM);
-            }
+            switch (w) { case 0: sweep_tiles1<0, N, M, PY>(S, lane); break; case 1: sweep_tiles1<1, N, M, PY>(S, lane); break;
+                         case 2: sweep_tiles1<2, N, M, PY>(S, lane); break; default: sweep_tiles1<3, N, M, PY>(S, lane); }
             if (tid < N) { double s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
         })
         SW_STAMP(1)
@@ -230,22 +259,8 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
-            for (int t = w; t < t3; t += 4) {
-                if (t < t1) {
-                    const int i0 = 16 * (t % TN), j0 = 16 * (t / TN);
-                    mfma_tile<true, N>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.A, LDN, S.HA, LDN);
-                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.C, LDM, S.lC, LDM);
-                } else if (t < t2) {
-                    const int i0 = 16 * ((t - t1) % TM), j0 = 16 * ((t - t1) / TM);
-                    mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, i0, j0, M, N, S.B, LDN, S.HA, LDN);
-                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, i0, j0, M, N, S.D, LDM, S.lC, LDM);
-                } else {
-                    const int i0 = 16 * ((t - t2) % TM), j0 = 16 * ((t - t2) / TM);
-                    mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.B, LDN, S.HB, LDN);
-                    if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.D, LDM, S.lD, LDM);
-                }
-            }
+            switch (w) { case 0: sweep_tiles2<0, N, M, PY>(S, lane); break; case 1: sweep_tiles2<1, N, M, PY>(S, lane); break;
+                         case 2: sweep_tiles2<2, N, M, PY>(S, lane); break; default: sweep_tiles2<3, N, M, PY>(S, lane); }
             if (tid < N) {
                 double s = 0;
                 _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, tid, LDN) * S.Gn[t];

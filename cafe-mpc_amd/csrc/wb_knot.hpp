@@ -26,13 +26,13 @@ struct WbCore {
     double h[18], Jall[12 * 18], Jdv[12], fpos[12], fvel[12];
     double JX[432];                    // Jc (12x18 compact active Jacobian) | Xm (18x12: L^-1 Jc^T or Minv Jc^T); also K / C staging
     double gam[12];
-    double GG[432];                    // G (144) | LG (144) | gval (72) | bar (72); the LQ program reuses it for the foot acc / vel tangents
+    double GG[288 + 2 * MAXG];         // G (144) | LG (144) | gval (MAXG) | bar (MAXG); the LQ program reuses it for the foot acc / vel tangents
     HD double* Jc() { return JX; }
     HD double* Xm() { return JX + 216; }
     HD double* G() { return GG; }
     HD double* LG() { return GG + 144; }
     HD double* gval() { return GG + 288; }
-    HD double* bar() { return GG + 360; }
+    HD double* bar() { return GG + 288 + MAXG; }
     HD double* dacc() { return GG; }          // LQ program: [3f+r][18] tangents of the foot accelerations
     HD double* dvel() { return GG + 216; }    // LQ program: [3f+r][18] tangents of the foot velocities (= footVelPartialDq)
     double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64], rdM[18], rdG[12];
@@ -315,6 +315,7 @@ HD double reb_barrier(double g, double delta) {   // ConstraintsBase.h:238-245
 // path-constraint value c (order: torque 24, joint 24, height 1, grf 5/foot) — MHPCConstraint.cpp
 HD double wb_constraint(const PhaseDev& P, const WbCore& L, int c) {
     if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) { int i = c - P.go_torque; return i < 12 ? -L.u[i] + P.torque_limit : L.u[i - 12] + P.torque_limit; }
+    if (P.go_jspeed >= 0 && c >= P.go_jspeed && c < P.go_jspeed + 24) { int i = c - P.go_jspeed; return i < 12 ? L.x[24 + i] - P.jspeed_lb : -L.x[24 + i - 12] + P.jspeed_ub; }
     if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) { int i = c - P.go_joint; return i < 12 ? L.x[6 + i] - P.joint_lb[i % 3] : -L.x[6 + i - 12] + P.joint_ub[i % 3]; }
     if (P.go_height >= 0 && c == P.go_height) return L.x[2] - P.h_min;
     int i = c - P.go_grf, a = i / 5, r = i % 5, f = P.feet[a];
@@ -391,8 +392,8 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
         P.lbase[(size_t)b * h + k] = lb;
         double l = lb;
         if (reb_active) {   // per constraint object: ReB_cost then l += dt*ReB_cost (SinglePhase.cpp:394-402)
-            int offs[4] = {P.go_torque, P.go_joint, P.go_height, P.go_grf}; int sz[4] = {24, 24, 1, 5 * P.nc};
-            for (int gI = 0; gI < 4; gI++) if (offs[gI] >= 0) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i]; l += P.dt * c; }
+            int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz);
+            for (int gI = 0; gI < nobj; gI++) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i]; l += P.dt * c; }
         }
         P.l[(size_t)b * h + k] = l;
         double ming = 0; for (int c = 0; c < P.ng; c++) ming = fmin(ming, L.gval()[c]);
@@ -603,6 +604,10 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
             lxd += dt * (D.bd()[P.go_joint + i] - D.bd()[P.go_joint + 12 + i]); diag += dt * (D.bdd()[P.go_joint + i] + D.bdd()[P.go_joint + 12 + i]);
         }
         if (P.go_height >= 0 && d == 2) { lxd += dt * D.bd()[P.go_height]; diag += dt * D.bdd()[P.go_height]; }
+        if (P.go_jspeed >= 0 && d >= 24) {
+            const int i = d - 24;
+            lxd += dt * (D.bd()[P.go_jspeed + i] - D.bd()[P.go_jspeed + 12 + i]); diag += dt * (D.bdd()[P.go_jspeed + i] + D.bdd()[P.go_jspeed + 12 + i]);
+        }
         D.W[d * 36 + d] += diag;
         P.lx[kk * P.rs + d] = lxd;
     })

@@ -270,3 +270,89 @@ def mhpc_problem(wb_schedule=((1, 1, 1, 1), (0, 1, 1, 0)), wb_horizons=(25, 25),
                 ph["Ubar"] = grf[:h].copy()
             phases.append(ph)
     return phases
+
+
+# ---- barrel roll (MHPC/MHPC-Trajopt/BarrelRoll/BarrelRollTO.cpp): values of setting/br_cost_weights.JSON,
+#      br_constraint_params.info and load_desired_final_states (BarrelRollTO.cpp:262-341), restated as data
+_BR_WEIGHTS = [
+    dict(qB=[0, 5, 10, 2, 2, 2], vB=[1, .1, 1, 1, 1, 1], qJ=[.01] * 3, vJ=[.01] * 3, rw=.2, fqB=[0, 1, 10, 2, 2, 10], fvB=[1, .5, 5, 2, 2, 5], fqJ=[.05] * 3, fvJ=[.1] * 3),
+    dict(qB=[0, 1, 10, 2, 2, 10], vB=[1] * 6, qJ=[.1] * 3, vJ=[.1] * 3, rw=.05, fqB=[0, 1, 10, 5, 5, 10], fvB=[1, 1, 5, 1, 1, 5], fqJ=[.1] * 3, fvJ=[.01] * 3),
+    dict(qB=[0, 1, 5, 2, 2, 2], vB=[1] * 6, qJ=[1, .1, .1], vJ=[.1] * 3, rw=.5, fqB=[0, 1, 5, 5, 5, 5], fvB=[1, 1, 2, 1, 1, 1], fqJ=[.5, .1, .1], fvJ=[.01] * 3),
+    dict(qB=[0, 1, 5, 2, 2, 2], vB=[1] * 6, qJ=[.1] * 3, vJ=[.1] * 3, rw=.1, fqB=[0, 1, 5, 5, 5, 10], fvB=[2, 2, .5, 1, 1, 1], fqJ=[.1] * 3, fvJ=[.01] * 3),
+    dict(qB=[0, 1, 5, 2, 2, 2], vB=[1, 1, .5, 1, 1, 1], qJ=[1] * 3, vJ=[.1] * 3, rw=.1, fqB=[0, 0, 1, 5, 5, 10], fvB=[2, 2, .2, 1, 1, 1], fqJ=[1] * 3, fvJ=[.01] * 3),
+    dict(qB=[0, 1, 5, 2, 2, 2], vB=[1] * 6, qJ=[.1] * 3, vJ=[.1] * 3, rw=.1, fqB=[0, 1, 5, 5, 5, 10], fvB=[2, 2, .5, 1, 1, 1], fqJ=[.1] * 3, fvJ=[.01] * 3),
+]
+
+
+def _br_state(pos, eul, qJ, v, euld):
+    return np.concatenate([pos, eul, qJ, v, euld, np.zeros(12)])
+
+
+def barrel_roll_states():
+    """xinit and the six desired phase-final states of BarrelRollTO.cpp (:93-105, 262-341)."""
+    pi = np.pi
+    xinit = _br_state([0, 0, 0.2183], [0, 0, 0], np.tile([0, -1.0, 2.0], 4), [0, 0, 0], [0, 0, 0])
+    q3 = np.array([0.3, -1.1, 2.2, -0.3, -1.1, 2.2, 0.3, -1.1, 2.2, -0.3, -1.1, 2.2])
+    xf = [
+        _br_state([0, -0.15, 0.26], [0, 0, pi / 6], np.tile([0, -1.2, 2.4], 4), [0, -1.0, 2.0], [0, 0, 3 * pi]),
+        _br_state([0, -0.25, 0.33], [0, 0, 0.5 * pi], np.tile([pi / 6, -1.0, 2.0, -pi / 5, -0.5, 1.0], 2), [0, -1.2, 2.0], [0, 0, 3 * pi]),
+        _br_state([0, -0.55, 0.22], [0, 0, 2 * pi], q3, [0, -1.5, -2.5], [0, 0, 3 * pi]),
+        _br_state([0, -0.55, 0.25], [0, 0, 2 * pi], q3, [0, 0, 0], [0, 0, 0]),
+        _br_state([0, -0.55, 0.25], [0, 0, 2 * pi], np.tile([0, -1.0, 2.0], 4), [0, 0, 0], [0, 0, 0]),
+        _br_state([0, -0.55, 0.25], [0, 0, 2 * pi], np.tile([0, -1.0, 2.0], 4), [0, 0, 0], [0, 0, 0]),
+    ]
+    return xinit, xf
+
+
+def barrel_roll_problem(switching_times=(0.0, 0.12, 0.33, 0.75, 0.90, 1.10, 1.25), dt=0.01,
+                        contacts=((1, 1, 1, 1), (0, 1, 0, 1), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 1, 1)), repeat=1):
+    """The barrel-roll trajectory optimisation of BarrelRollTO.cpp: 6 hybrid phases (stance, right-side stance,
+    flight, landing, flight, stance), tracking cost towards a constant per-phase target, torque / joint-speed /
+    joint / height / GRF barriers and a four-foot touchdown constraint at the end of the flight phases.
+    Returns (phases, xinit).  `repeat` > 1 chains the last four phases again ("running" variant, BASELINE config 3)."""
+    xinit, xf = barrel_roll_states()
+    sw = list(switching_times); cts = list(contacts); tgt = list(xf); wts = list(_BR_WEIGHTS)
+    for _ in range(repeat - 1):   # flight -> landing pairs appended with the same durations
+        for j in (4, 5):
+            sw.append(sw[-1] + (switching_times[j + 1] - switching_times[j])); cts.append(contacts[j]); tgt.append(xf[j]); wts.append(_BR_WEIGHTS[j])
+    nph = len(cts)
+    phases = []
+    for i in range(nph):
+        h = int(round((sw[i + 1] - sw[i]) / dt))
+        nxt = cts[i + 1] if i + 1 < nph else cts[i]
+        w = wts[i]
+        xr = np.tile(tgt[i], (h + 1, 1))
+        rc = np.tile(np.array(cts[i], dtype=np.int32), (h + 1, 1))
+        refs = dict(xr=xr, ur=np.zeros((h + 1, 12)), yr=np.zeros((h + 1, 12)), foot_pos=np.zeros((h + 1, 12)), foot_vel=np.zeros((h + 1, 12)),
+                    body_pos=xr[:, :3].copy(), ref_contact=rc)
+        ph = wb_phase(h, dt, sw[i], cts[i], nxt, refs, ubar_mode="zero")
+        d = ph["desc"]
+        _set(d.q, list(w["qB"]) + list(w["qJ"]) * 4 + list(w["vB"]) + list(w["vJ"]) * 4)
+        _set(d.r, [w["rw"]] * 12)
+        _set(d.qf, list(w["fqB"]) + list(w["fqJ"]) * 4 + list(w["fvB"]) + list(w["fvJ"]) * 4)
+        _set(d.w_foot_reg, [-1, 0, 0]); _set(d.w_swing_pos, [-1, 0, 0]); _set(d.w_swing_vel, [-1, 0, 0]); d.w_td_vel = -1.0   # tracking cost only
+        d.c_jointspeed, d.jointspeed_lb, d.jointspeed_ub = 1, -20.0, 20.0
+        d.h_min = 0.13
+        d.reb_grf = Reb(0.02, 0.02, 0.1); d.reb_torque = Reb(0.01, 0.01, 0.1); d.reb_jointspeed = Reb(0.1, 0.1, 0.1)
+        d.reb_joint = Reb(0.01, 0.01, 0.1); d.reb_minheight = Reb(0.01, 0.01, 0.1)
+        d.al_td = Al(20.0, 0.0, 1e4)
+        # initial guess: linear interpolation between consecutive targets with float time accumulation (BarrelRollTO.cpp:131-145)
+        x_from = xinit if i == 0 else tgt[i - 1]
+        t = np.float32(0.0); dur = np.float32(sw[i + 1] - sw[i])
+        X = np.zeros((h + 1, 36))
+        for k in range(h + 1):
+            X[k] = x_from + (tgt[i] - x_from) * float(t / dur)
+            t = np.float32(t + np.float32(dt))
+        ph["Xbar"] = X
+        phases.append(ph)
+    return phases, xinit
+
+
+def br_ddp_setting(**kw):
+    """br_ddp_setting.info as loadHSDDPSetting reads it (update_regularization stays at the struct default 2: quirk xiii)."""
+    from ._abi import mhpc_ddp_setting
+    base = dict(alpha=0.5, gamma=0.1, update_penalty=5, update_relax=1, update_ReB=1, max_DDP_iter=10, max_AL_iter=30,
+                cost_thresh=1e-2, tconstr_thresh=1e-3, pconstr_thresh=1e-3, dynamics_feas_thresh=1e-3, merit_scale=0.1, merit_offset=1,
+                AL_active=1, ReB_active=1, MS=1)
+    base.update(kw)
+    return mhpc_ddp_setting(**base)

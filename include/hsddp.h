@@ -73,6 +73,11 @@ typedef struct hsddp_phase_desc {
     double h_min;                 /* 0.20 WB / 0.18 SRB */
     double mu;                    /* 0.6 WB / 0.7 SRB,HKD */
     hsddp_reb_t reb_torque, reb_joint, reb_minheight, reb_grf;
+    /* joint-speed box on x[24..35] (BarrelRoll::JointSpeedLimit, BarrelRoll/BarrelRollConstraints.cpp:143-186); placed
+     * after the torque limit in the constraint list like BarrelRollTO.cpp:178-199 does */
+    int c_jointspeed;
+    double jointspeed_lb, jointspeed_ub;   /* -20 / 20 (BarrelRollConstraints.h:69-70) */
+    hsddp_reb_t reb_jointspeed;
     /* terminal touchdown constraint (WBTouchDown, MHPCConstraint.cpp:238-288), added iff a touchdown follows */
     int c_touchdown;
     double ground_height;

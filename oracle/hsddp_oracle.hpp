@@ -92,6 +92,12 @@ struct Solver {
                 for (int i = 0; i < 12; i++) P.cons.push_back({1, 1, {i, 0, 0}, {1, 0, 0}, d.torque_limit});
                 add_group(f, d.reb_torque);
             }
+            if (d.c_jointspeed) {   // BarrelRoll::JointSpeedLimit (BarrelRoll/BarrelRollConstraints.cpp:143-186), added right after the torque limit
+                int f = P.cons.size();
+                for (int i = 0; i < 12; i++) P.cons.push_back({0, 1, {24 + i, 0, 0}, {1, 0, 0}, -d.jointspeed_lb});
+                for (int i = 0; i < 12; i++) P.cons.push_back({0, 1, {24 + i, 0, 0}, {-1, 0, 0}, d.jointspeed_ub});
+                add_group(f, d.reb_jointspeed);
+            }
             if (d.c_joint) {   // JointLimit (MHPCConstraint.cpp:163-204)
                 int f = P.cons.size();
                 for (int i = 0; i < 12; i++) P.cons.push_back({0, 1, {6 + i, 0, 0}, {1, 0, 0}, -d.joint_lb[i % 3]});

@@ -42,9 +42,15 @@ def _srb_x0(x0):
     return np.ascontiguousarray(x0[:, list(range(6)) + list(range(18, 24))])     # StateProjection (MHPCReset.h:24-26)
 
 
-@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only"])
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll"])
 def test_per_iterate_parity(hip_lib, oracle_lib, which):
     x0 = pkg.problems.wb_ensemble_x0(3, 20241222)
+    if which == "barrel_roll":   # BarrelRollTO.cpp at short phase durations; conditioning note in test_kernel_logic_emu.py
+        phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.05, 0.11, 0.18, 0.23, 0.29, 0.34))
+        x0 = np.vstack([xinit, xinit + 0.01 * (x0[:2] - pkg.problems.wb_nominal_state())])
+        so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+        pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, rtol=1e-6)
+        return
     if which == "mhpc":        # whole-body phases + single-rigid-body tail (state dimension 36 -> 12 across the impact reset)
         phases = pkg.problems.mhpc_problem(wb_horizons=(7, 6), srb_horizons=(5, 4))
     elif which == "srb_only":
@@ -75,6 +81,24 @@ def test_full_solve_parity_mhpc(hip_lib, oracle_lib):
     so.solve(opt); sg.solve(opt)
     pc.compare_solve(so, sg, len(phases))
     assert (sg.info_arrays()["n_iters"] >= 2).all()
+
+
+def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib):
+    """BarrelRollTO.cpp as shipped: 6 hybrid phases / 125 knots (stance, right-side stance, flight, landing, flight, stance),
+    zero-torque start, br_ddp_setting.info; the first AL iteration (10 DDP iterations, line searches down to small steps)."""
+    phases, xinit = pkg.problems.barrel_roll_problem()
+    x0 = np.vstack([xinit, xinit])
+    x0[1, 6:18] += 0.02
+    opt = pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=4)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    for k in ("n_iters", "n_ls_iters", "n_reg_iters", "status"):
+        assert np.array_equal(ia[k], ib[k]), (k, ia[k], ib[k])
+    # a 125-knot zero-torque start amplifies rounding differences between the two factorisations: compare the iterate loosely
+    # (1e-4 relative) and the control flow exactly
+    assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=1e-5)
+    pc.compare(so, sg, ["XBAR", "UBAR"], len(phases), 1e-4, "barrel_roll_solve")
 
 
 def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):
