@@ -45,9 +45,10 @@ def run_steps(pkg, sa, sb, phases, opt, n_iter=2, rtol=1e-8, atol_K=1e-6):
             s.hybrid_rollout(eps, opt); s.compute_cost(opt)
         compare(sa, sb, STEP_FIELDS["rollout"], nph, rtol, f"rollout{it}")
         fa, fb = sa.measure_dynamics_feasibility(), sb.measure_dynamics_feasibility()
-        assert np.allclose(fa, fb, rtol=1e-10, atol=1e-12)
+        rs = max(1e-10, 1e-2 * rtol)     # scalars: 1e-10 at the default per-iterate tolerance
+        assert np.allclose(fa, fb, rtol=rs, atol=1e-12), (fa, fb)
         ia, ib = sa.info_arrays(), sb.info_arrays()
-        assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=1e-10, atol=1e-10)
+        assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=rs, atol=1e-10), (ia["actual_cost"], ib["actual_cost"])
         if it == 0:
             for s in (sa, sb):
                 s.update_nominal_trajectory()

@@ -49,7 +49,9 @@ def test_per_iterate_parity(hip_lib, oracle_lib, which):
         phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.05, 0.11, 0.18, 0.23, 0.29, 0.34))
         x0 = np.vstack([xinit, xinit + 0.01 * (x0[:2] - pkg.problems.wb_nominal_state())])
         so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-        pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, rtol=1e-6)
+        # gains reach |K| ~ 250 on this iterate: K is held to 1e-7 RELATIVE here (2.5e-5 absolute at that scale), every other
+        # case in this file keeps north_star's 1e-6 absolute bound
+        pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, rtol=1e-7, atol_K=None)
         return
     if which == "mhpc":        # whole-body phases + single-rigid-body tail (state dimension 36 -> 12 across the impact reset)
         phases = pkg.problems.mhpc_problem(wb_horizons=(7, 6), srb_horizons=(5, 4))
