@@ -10,6 +10,12 @@
 
 namespace hs {
 
+// reset maps that exist in the reference: WB->WB, WB->SRB (MHPCReset.cpp:4-52), SRB->SRB (identity), HKD->HKD (HKDReset.h)
+inline bool phase_chain_ok(int model, int next_model) {
+    if (model == HSDDP_MODEL_WB) return next_model == HSDDP_MODEL_WB || next_model == HSDDP_MODEL_SRB;
+    return model == next_model;
+}
+
 // Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes);
 //             void replicate(void* base, size_t bytes_one, size_t count): copies record 0 into records 1..count-1
 template <class Mem>
@@ -41,9 +47,11 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     if (wb && d.c_jointspeed) { P.go_jspeed = ng; ng += 24; }
     if (wb && d.c_joint) { P.go_joint = ng; ng += 24; }
     if (d.c_minheight) { P.go_height = ng; ng += 1; }
-    if (wb && d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
-    if (!wb) { P.n_td = 0; P.has_impact = 0; for (int l = 0; l < 4; l++) P.td[l] = 0; }
-    P.ng = ng; P.nt = (wb && d.c_touchdown) ? P.n_td : 0; P.slot0 = slot0;
+    const bool hkd = d.model == HSDDP_MODEL_HKD, srb = d.model == HSDDP_MODEL_SRB;
+    if (hkd) { ng = 0; P.go_height = -1; }                      // the HKD problem has the GRF pyramid only (HKDProblem.cpp:262-271)
+    if ((wb || hkd) && d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
+    if (srb) { P.n_td = 0; P.has_impact = 0; for (int l = 0; l < 4; l++) P.td[l] = 0; }
+    P.ng = ng; P.nt = (!srb && d.c_touchdown) ? P.n_td : 0; P.slot0 = slot0;
     const size_t h1 = P.h + 1, hh = P.h;
     bool ok = true;
     auto up = [&](const double** dst, const double* src, size_t cnt) { void* p = mem.alloc(cnt * 8); if (!p) { ok = false; return; } if (src) mem.upload(p, src, cnt * 8); *dst = (const double*)p; };

@@ -17,6 +17,7 @@
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
 #include "srb_knot.hpp"
+#include "hkd_knot.hpp"
 #include "sweep.hpp"
 
 using namespace hs;
@@ -54,6 +55,12 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, in
     const PhaseDev& P = ph[pi];
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
     const size_t slot = (size_t)b * nslots + s;
+    if (P.model == HSDDP_MODEL_HKD) {
+        HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
+        if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
+        else hkd_rollout_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
+        return;
+    }
     if (P.model == HSDDP_MODEL_SRB) {   // reduced-model tail of the MHPC horizon: a few hundred flops per knot, reuses the whole-body LDS block
         SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
         if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
@@ -71,6 +78,11 @@ __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, 
     __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
     const PhaseDev& P = ph[pi];
+    if (P.model == HSDDP_MODEL_HKD) {
+        HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
+        if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+        return;
+    }
     if (P.model == HSDDP_MODEL_SRB) {
         SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
         if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
@@ -131,14 +143,14 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph, in
     }
     if (success && do_linear) linear_rollout<SW_NT>(S, ph, nph, b, lin_eps);
     __syncthreads();
-    if (threadIdx.x == 0) { st[b].dV_1 = S.dV1; st[b].dV_2 = S.dV2; }
+    if (threadIdx.x == 0) { st[b].dV_1 = S.c.dV1; st[b].dV_2 = S.c.dV2; }
 }
 
 __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph, int nph, ProbState* st, double eps) {
     __shared__ SweepLds S;
     linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
     __syncthreads();
-    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.dV1; st[blockIdx.x].dV_2 = S.dV2; }
+    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
 }
 
 // X -> Xbar, U -> Ubar, Defect -> Defect_bar (Trajectory::update_nominal_vals, TrajectoryManagement.cpp:122-127)
@@ -345,8 +357,8 @@ void hsddp_destroy(hsddp_handle_t* h) {
 int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
     if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
     for (int i = 0; i < n_phases; i++) {
-        if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB) { fprintf(stderr, "[hsddp_hip] phase %d: model %d (HKD) does not run on the HIP backend in this build\n", i, phases[i].model); return HSDDP_ENOTSUP; }
-        if (i > 0 && phases[i].model == HSDDP_MODEL_WB && phases[i - 1].model != HSDDP_MODEL_WB) { fprintf(stderr, "[hsddp_hip] phase %d: no reset map from a reduced model back to the whole-body model (MHPCReset.cpp has none either)\n", i); return HSDDP_ENOTSUP; }
+        if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB && phases[i].model != HSDDP_MODEL_HKD) return HSDDP_EINVAL;
+        if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) { fprintf(stderr, "[hsddp_hip] phase %d: the reference has no reset map from model %d to model %d (MHPCReset.cpp:4-52, HKDReset.h)\n", i, phases[i - 1].model, phases[i].model); return HSDDP_ENOTSUP; }
         if (!phases[i].shooting) { fprintf(stderr, "[hsddp_hip] single-shooting phases are not supported (knot-parallel multiple shooting only)\n"); return HSDDP_ENOTSUP; }
         if (phases[i].horizon <= 0) return HSDDP_EINVAL;
     }

@@ -24,9 +24,7 @@
 namespace hs {
 
 constexpr int SW_NT = 256;
-constexpr int SW_N = 36, SW_M = 12, SW_P = 12;   // dimension bound of this build (whole-body phases)
-constexpr int LDN = 37;     // padded leading dimension of n-row matrices
-constexpr int LDM = 13;     // padded leading dimension of m-row / p-row matrices
+constexpr int SW_N = 36;    // largest state dimension of any model
 constexpr int SW_PRE = 20;  // prefetch registers per thread
 #ifndef SW_UNROLL_N
 #define SW_UNROLL_N 4
@@ -37,26 +35,33 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 #define SW_MINB 2
 #endif
 
-struct SweepLds {
-    double H[LDN * SW_N], A[LDN * SW_N], HA[LDN * SW_N], Qxx[LDN * SW_N];
-    double B[LDN * SW_M], HB[LDN * SW_M];
-    double Qux[LDM * SW_N], K[LDM * SW_N], C[LDM * SW_N], lC[LDM * SW_N];
-    double D[LDM * SW_M], lD[LDM * SW_M], lyy[LDM * SW_P], Quu[LDM * SW_M], LQ[LDM * SW_M], Qi[LDM * SW_M];
-    double G[SW_N], Gn[SW_N], Qx[SW_N], Qu[SW_M], dU[SW_M], ly[SW_P], def[SW_N], rdQ[SW_M];
-    double dx[SW_N], dxn[SW_N], du[SW_M];
+// LDS working set of one Riccati step for a model with dims (N, M, PY); leading dimensions padded to rows + 1
+// (conflict-free column access).  All three instantiations are views over the same raw LDS block (SweepLds).
+template <int N, int M, int PY> struct SweepLdsT {
+    static constexpr int LDN = N + 1, LDM = (M > PY ? M : PY) + 1, PYd = PY > 0 ? PY : 1;
+    double H[LDN * N], A[LDN * N], HA[LDN * N], Qxx[LDN * N];
+    double B[LDN * M], HB[LDN * M];
+    double Qux[LDM * N], K[LDM * N], C[PY > 0 ? LDM * N : 1], lC[PY > 0 ? LDM * N : 1];
+    double D[PY > 0 ? LDM * M : 1], lD[PY > 0 ? LDM * M : 1], lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M], LQ[LDM * M];
+    double G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N], rdQ[M];
+    double dx[N], dxn[N], du[M];
     double red[SW_NT];
-    double dV1, dV2;
-    unsigned long long t_last;
-    int ok;
 };
+// what survives a phase boundary: value-function gradient / state deviation handed to the neighbouring phase, dV, status
+struct SweepCtl { double dV1, dV2, xfer[SW_N]; unsigned long long t_last; int ok; };
+using SweepWB = SweepLdsT<36, 12, 12>;
+using SweepSRB = SweepLdsT<12, 12, 0>;
+using SweepHKD = SweepLdsT<24, 24, 0>;
+struct SweepLds { double raw[sizeof(SweepWB) / sizeof(double)]; SweepCtl c; };
+static_assert(sizeof(SweepHKD) <= sizeof(SweepWB) && sizeof(SweepSRB) <= sizeof(SweepWB), "the whole-body view is the largest");
 
 #define CM(M, i, j, ld) (M)[(i) + (ld) * (j)]
 
 // optional in-kernel stamps (diagnostic builds only: -DSW_PROF): cycles per phase group, block 0 / thread 0
 #if defined(SW_PROF) && !defined(HS_HOST_EMU)
 __device__ unsigned long long g_sw_prof[16];
-#define SW_STAMP(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_sw_prof[i], t_ - S.t_last); S.t_last = t_; } }
-#define SW_STAMP0() { if (blockIdx.x == 0 && threadIdx.x == 0) S.t_last = clock64(); }
+#define SW_STAMP(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_sw_prof[i], t_ - SWC.t_last); SWC.t_last = t_; } }
+#define SW_STAMP0() { if (blockIdx.x == 0 && threadIdx.x == 0) SWC.t_last = clock64(); }
 #else
 #define SW_STAMP(i)
 #define SW_STAMP0()
@@ -197,7 +202,8 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
 template <int W, int N, int M, int PY>
-HD void sweep_tiles1(SweepLds& S, int lane) {
+HD void sweep_tiles1(SweepLdsT<N, M, PY>& S, int lane) {
+    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
     _Pragma("unroll") for (int t = W; t < t4; t += 4) {
@@ -208,7 +214,8 @@ HD void sweep_tiles1(SweepLds& S, int lane) {
     }
 }
 template <int W, int N, int M, int PY>
-HD void sweep_tiles2(SweepLds& S, int lane) {
+HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
+    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
     _Pragma("unroll") for (int t = W; t < t3; t += 4) {
@@ -230,16 +237,18 @@ HD void sweep_tiles2(SweepLds& S, int lane) {
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
-HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
-    using RL = RecLayout<N, M, PY>;
-    static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && M <= SW_M && N <= SW_N && PY <= SW_P, "sweep limits");
+HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
+    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
+    static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M, "sweep limits");
+    constexpr int LDN = ST::LDN, LDM = ST::LDM;
+    ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
     const int h = P.h;
     SW_PRE_DECL
     // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327); prefetch knot h-1
     HS_PHASE(NT, { const int i = tid % N, j0 = tid / N; if (j0 < NT / N) for (int j = j0; j < N; j += NT / N) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * N * N + i + N * j]; }
-             if (tid < N) { S.G[tid] += P.Phix[(size_t)b * N + tid]; P.G[((size_t)b * (h + 1) + h) * N + tid] = S.G[tid]; }
-             if (tid == 0) { S.ok = 1; }
+             if (tid < N) { const double g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; P.G[((size_t)b * (h + 1) + h) * N + tid] = g; }
+             if (tid == 0) { SWC.ok = 1; }
              SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1))
     for (int k = h - 1; k >= 0; k--) {
         const size_t kk = (size_t)b * h + k;
@@ -280,7 +289,7 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         HS_PHASE_L(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
-        chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &S.ok);
+        chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &SWC.ok);
         // K = -Quu^-1 Qux and dU = -Quu^-1 Qu by two triangular solves per column (lanes 0..N-1: columns of Qux, lane N: Qu);
         // the reference forms Quu_inv = LDLT.solve(I) and multiplies (SinglePhase.cpp:375-380): same result to rounding
         HS_WPHASE(if (tid <= N) {
@@ -294,14 +303,14 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
         HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) { const int i = e % N, j = e / N; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
         SW_STAMP(5)
-        if (!S.ok) return false;
+        if (!SWC.ok) return false;
         SW_STAMP(6)
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
               for (int tile = w; tile < TN * TN; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % TN), 16 * (tile / TN), N, N, S.Qux, LDM, S.K, LDM); }
             if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
-            else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; S.dV1 -= dVk; S.dV2 += dVk; }
+            else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
         HS_PHASE_L(NT, st_mat<NT>(tid, P.K + kk * M * N, S.K, LDM, M, N);)
@@ -310,32 +319,44 @@ HD bool riccati_phase(SweepLds& S, const PhaseDev& P, int b, double reg) {
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
     HS_PHASE(NT, if (tid < N) S.def[tid] = P.Defect[((size_t)b * (h + 1)) * N + tid];)
     HS_PHASE(NT, if (tid < N) { double s = S.G[tid]; for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
-    HS_PHASE(NT, if (tid < N) { S.G[tid] = S.Gn[tid]; P.G[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
+    HS_PHASE(NT, if (tid < N) { SWC.xfer[tid] = S.Gn[tid]; P.G[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
              st_mat<NT>(tid, P.H0 + (size_t)b * N * N, S.H, LDN, N, N);)
     return true;
 }
 
-// full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, SRB 12/12/0);
-// returns success, writes dV into S.dV1/dV2
+// full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, HKD 24/24/0, SRB 12/12/0);
+// returns success, writes dV into S.c.dV1/dV2.  H of the phase being processed sits at the start of the raw block with
+// ld n+1 in every view; the gradient G crosses phase boundaries through S.c.xfer.
 template <int NT>
 HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
-    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; })
+    HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
         const PhaseDev& P = ph[i];
         const int n = P.n;
         if (i == nph - 1) {
-            HS_PHASE(NT, for (int e = tid; e < LDN * n; e += NT) S.H[e] = 0.0; if (tid < n) S.G[tid] = 0.0;)
-        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = nn x n  (MultiPhaseDDP.cpp:196-201); once per phase boundary
-            const int nn = P.next_n;
-            HS_PHASE(NT, ld_mat<NT>(tid, S.A, LDN, P.Px + (size_t)b * nn * n, nn, n);)
+            HS_PHASE(NT, for (int e = tid; e < (n + 1) * n; e += NT) S.raw[e] = 0.0; if (tid < n) S.c.xfer[tid] = 0.0;)
+        } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = nn x n, nn <= n  (MultiPhaseDDP.cpp:196-201); once per phase boundary
+            const int nn = P.next_n, ldh = nn + 1;
+            double* Hn = S.raw;                          // H of the later phase: nn x nn, ld nn+1
+            double* Px = S.raw + (n + 1) * n;            // scratch in the A / HA regions of the current view (beyond Hn because n >= nn)
+            double* HP = S.raw + 2 * (n + 1) * n;
+            const double* Pxg = P.Px + (size_t)b * nn * n;
+            double gnew = 0.0;
+            HS_PHASE(NT, for (int e = tid; e < nn * n; e += NT) Px[e] = Pxg[e];)
             HS_PHASE(NT,
-                for (int e = tid; e < nn * n; e += NT) { const int r = e % nn, c = e / nn; double s = 0; for (int t = 0; t < nn; t++) s += CM(S.H, r, t, LDN) * CM(S.A, t, c, LDN); CM(S.HA, r, c, LDN) = s; }
-                if (tid >= NT - n) { const int i2 = tid - (NT - n); double s = 0; for (int t = 0; t < nn; t++) s += CM(S.A, t, i2, LDN) * S.G[t]; S.Gn[i2] = s; })
+                for (int e = tid; e < nn * n; e += NT) { const int r = e % nn, c = e / nn; double s = 0; for (int t = 0; t < nn; t++) s += Hn[r + ldh * t] * Px[t + nn * c]; HP[e] = s; }
+                if (tid >= NT - n) { const int i2 = tid - (NT - n); double s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * i2] * S.c.xfer[t]; S.raw[3 * (n + 1) * n + i2] = s; })
+            (void)gnew;
             HS_PHASE(NT,
-                for (int e = tid; e < n * n; e += NT) { const int r = e % n, c = e / n; double s = 0; for (int t = 0; t < nn; t++) s += CM(S.A, t, r, LDN) * CM(S.HA, t, c, LDN); CM(S.H, r, c, LDN) = s; }
-                if (tid >= NT - n) S.G[tid - (NT - n)] = S.Gn[tid - (NT - n)];)
+                for (int e = tid; e < n * n; e += NT) { const int r = e % n, c = e / n; double s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * r] * HP[t + nn * c]; S.raw[r + (n + 1) * c] = s; }
+                if (tid >= NT - n) S.c.xfer[tid - (NT - n)] = S.raw[3 * (n + 1) * n + tid - (NT - n)];)
         }
-        const bool ok = (P.n == 36) ? riccati_phase<NT, 36, 12, 12>(S, P, b, reg) : riccati_phase<NT, 12, 12, 0>(S, P, b, reg);
+        bool ok;
+        switch (P.model) {
+            case HSDDP_MODEL_WB: ok = riccati_phase<NT, 36, 12, 12>(S, P, b, reg); break;
+            case HSDDP_MODEL_SRB: ok = riccati_phase<NT, 12, 12, 0>(S, P, b, reg); break;
+            default: ok = riccati_phase<NT, 24, 24, 0>(S, P, b, reg); break;
+        }
         if (!ok) return false;
     }
     return true;
@@ -357,15 +378,16 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
     { const double v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
       if (tid < N) S.Qx[tid] = v_; else if (tid < N + M) S.Qu[tid - N] = v_; else if (tid < N + 2 * M) S.dU[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) S.def[tid - N - 2 * M] = v_; } }
 
-// one phase of the linear rollout; on entry S.dxn holds dx_init (Px * dX_end of the previous phase, or 0)
+// one phase of the linear rollout; on entry S.c.xfer holds dx_init (Px * dX_end of the previous phase, or 0), on exit dX_end
 template <int NT, int N, int M, int PY>
-HD void linear_phase(SweepLds& S, const PhaseDev& P, int b, double eps) {
-    using RL = RecLayout<N, M, PY>;
-    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE, "prefetch registers");
+HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
+    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
+    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 128 + M <= NT - 64, "prefetch registers / lane maps");
+    ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
     SW_PRE_DECL
     // dX[0] = dx_init + eps * Defect[0]
-    HS_PHASE(NT, if (tid < N) { double v = S.dxn[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
+    HS_PHASE(NT, if (tid < N) { double v = SWC.xfer[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
              SW_LIN_FETCH((size_t)b * h, 0))
     for (int k = 0; k < h; k++) {
         const size_t kk = (size_t)b * h + k;
@@ -390,27 +412,33 @@ HD void linear_phase(SweepLds& S, const PhaseDev& P, int b, double eps) {
             double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
             for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
             for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
-            S.dV1 += a1 + b1; S.dV2 += a2; S.dV2 += b2;      // (+ du^T lux dx with lux == 0)
+            SWC.dV1 += a1 + b1; SWC.dV2 += a2; SWC.dV2 += b2;      // (+ du^T lux dx with lux == 0)
         } if (tid >= 64 && tid < 64 + N) S.dx[tid - 64] = S.dxn[tid - 64];)
     }
     // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx
     HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
     HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * N + tid] * S.dx[tid]; })
-    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } S.dV1 += a1; S.dV2 += a2; })
+    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } SWC.dV1 += a1; SWC.dV2 += a2; }
+             if (tid >= 64 && tid < 64 + N) SWC.xfer[tid - 64] = S.dx[tid - 64];)
 }
 
-// linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.dV1/dV2.
+// linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
 template <int NT>
 HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
-    HS_PHASE(NT, if (tid == 0) { S.dV1 = 0.0; S.dV2 = 0.0; } if (tid < SW_N) S.dxn[tid] = 0.0;)
+    HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; } if (tid < SW_N) S.c.xfer[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
         const PhaseDev& P = ph[i];
-        if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); S.dx holds the previous phase's terminal dX
+        if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); xfer holds the previous phase's terminal dX
             const PhaseDev& Pp = ph[i - 1]; const int np = Pp.n, n = P.n;
-            HS_PHASE(NT, for (int e = tid; e < n * np; e += NT) S.A[e] = Pp.Px[(size_t)b * n * np + e];)
-            HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += CM(S.A, tid, t, n) * S.dx[t]; S.dxn[tid] = s; })
+            const double* Pxg = Pp.Px + (size_t)b * n * np;
+            HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += Pxg[tid + n * t] * S.c.xfer[t]; S.raw[tid] = s; })
+            HS_PHASE(NT, if (tid < n) S.c.xfer[tid] = S.raw[tid];)
         }
-        if (P.n == 36) linear_phase<NT, 36, 12, 12>(S, P, b, eps); else linear_phase<NT, 12, 12, 0>(S, P, b, eps);
+        switch (P.model) {
+            case HSDDP_MODEL_WB: linear_phase<NT, 36, 12, 12>(S, P, b, eps); break;
+            case HSDDP_MODEL_SRB: linear_phase<NT, 12, 12, 0>(S, P, b, eps); break;
+            default: linear_phase<NT, 24, 24, 0>(S, P, b, eps); break;
+        }
     }
 }
 

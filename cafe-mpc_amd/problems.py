@@ -8,7 +8,7 @@ MHPC/settings/constraint_params_regular.info, limits from MHPCConstraint.{h,cpp}
 import ctypes as C
 import numpy as np
 
-from ._abi import PhaseDesc, Reb, Al, MODEL_WB, MODEL_SRB, MODEL_DIMS, DP, IP
+from ._abi import PhaseDesc, Reb, Al, MODEL_WB, MODEL_SRB, MODEL_HKD, MODEL_DIMS, DP, IP
 
 QJ_NOM = np.array([0.0, -1.0, 2.0] * 4)            # Loco_TO.cpp:53
 Z_NOM = 0.2183                                      # Loco_TO.cpp:54
@@ -353,6 +353,90 @@ def br_ddp_setting(**kw):
     from ._abi import mhpc_ddp_setting
     base = dict(alpha=0.5, gamma=0.1, update_penalty=5, update_relax=1, update_ReB=1, max_DDP_iter=10, max_AL_iter=30,
                 cost_thresh=1e-2, tconstr_thresh=1e-3, pconstr_thresh=1e-3, dynamics_feas_thresh=1e-3, merit_scale=0.1, merit_offset=1,
+                AL_active=1, ReB_active=1, MS=1)
+    base.update(kw)
+    return mhpc_ddp_setting(**base)
+
+
+# ---- hybrid kinodynamic model (HKDMPC/HKD-TrajOpt): x = [eul, pos, omega, v, qdummy(12)], u = [GRF(12), qJdot(12)],
+#      legs FR, FL, HR, HL
+HKD_LEG_TO_WB = (1, 0, 3, 2)
+
+
+def hkd_phase(horizon, dt, t_offset, contact, next_contact, refs):
+    """One HKD phase as HKDProblem::create_problem_one_phase / add_tconstr_one_phase assemble it (HKDProblem.cpp:236-323):
+    HKDTrackingCost weights (HKDCost.h:10-40), HKDFootPlaceReg (Qfoot = 100 on stance-foot x,y; HKDCost.h:55-76),
+    GRF pyramid on u (mu 0.7) and the touchdown constraint, parameters of HKDMPC/settings/constraint_params.info."""
+    d = PhaseDesc()
+    d.model, d.horizon, d.dt, d.t_offset = MODEL_HKD, horizon, dt, t_offset
+    _set(d.contact, contact); _set(d.next_contact, next_contact)
+    d.next_model, d.shooting, d.BG_alpha = MODEL_HKD, 1, 0.0
+    q = [1, 4, 4, 1, 1, 30, 1.0, 0.5, 0.2, 1, 1, 1] + [0.1 * (1 - contact[l]) for l in range(4) for _ in range(3)]
+    scale = [1, 1, 2, 1, 1, 20, 1.0, 0.2, 0.1, 1, 1, 1] + [0.01] * 12
+    _set(d.q, q); _set(d.qf, [20 * s * w for s, w in zip(scale, q)]); _set(d.r, [0.1] * 24)
+    _set(d.w_foot_reg, [100.0, 100.0, 0.0]); _set(d.w_swing_pos, [-1, 0, 0]); _set(d.w_swing_vel, [-1, 0, 0]); d.w_td_vel = -1.0
+    d.c_grf, d.mu = 1, 0.7
+    d.reb_grf = Reb(0.1, 0.1, 0.5)
+    d.c_touchdown, d.ground_height = 1, 0.0
+    d.al_td = Al(20.0, 0.0, 1e4)
+    bufs = {}
+    for name, w in (("xr", 24), ("ur", 24), ("foot_pos", 12), ("foot_vel", 12), ("body_pos", 3)):
+        a = np.ascontiguousarray(refs[name], dtype=np.float64); assert a.shape == (horizon + 1, w), (name, a.shape)
+        bufs[name] = a; setattr(d, name, a.ctypes.data_as(DP))
+    rc = np.ascontiguousarray(refs["ref_contact"], dtype=np.int32); bufs["ref_contact"] = rc; d.ref_contact = rc.ctypes.data_as(IP)
+    return {"desc": d, "bufs": bufs, "Xbar": bufs["xr"].copy(), "Ubar": bufs["ur"][:horizon].copy()}
+
+
+def hkd_trot_problem(schedule=((1, 1, 1, 1), (1, 0, 0, 1), (0, 1, 1, 0), (1, 0, 0, 1)), horizons=(10, 10, 10, 10), dt=0.01, vx=0.5,
+                     last_next=(0, 1, 1, 0)):
+    """BASELINE config 4 in shape: HKDMPC trot (diagonal pairs FR+HL / FL+HR), synthetic references built the way
+    HKDSinglePhaseReference::get_reference_at_t lays them out (HKDReference.cpp:23-61): stance legs track the planned
+    foothold, swing legs the nominal joint angles; GRF reference = weight split over the stance feet."""
+    nph = len(schedule)
+    t0 = np.concatenate([[0.0], np.cumsum([h * dt for h in horizons])])
+    feet_wb = wb_foot_positions(wb_nominal_state()[:18]); feet_wb[:, 2] = 0.0
+    feet = feet_wb[list(HKD_LEG_TO_WB)]          # nominal footholds under the hips, HKD leg order
+
+    def foothold(i, f):
+        i = min(max(i, 0), nph - 1)
+        return feet[f] + np.array([vx * 0.5 * (t0[i] + t0[i + 1]), 0, 0])
+
+    phases = []
+    for i in range(nph):
+        h = horizons[i]; c = schedule[i]
+        nxt = schedule[i + 1] if i + 1 < nph else last_next
+        xr = np.zeros((h + 1, 24)); ur = np.zeros((h + 1, 24)); fp = np.zeros((h + 1, 12)); bp = np.zeros((h + 1, 3))
+        rc = np.tile(np.array(c, dtype=np.int32), (h + 1, 1))
+        nc = max(1, int(np.sum(c)))
+        for k in range(h + 1):
+            t = t0[i] + k * dt
+            bp[k] = [vx * t, 0.0, Z_NOM]
+            xr[k, 3:6] = bp[k]; xr[k, 9] = vx
+            for f in range(4):
+                fp[k, 3 * f:3 * f + 3] = foothold(i if c[f] else i + 1, f)
+                xr[k, 12 + 3 * f:15 + 3 * f] = fp[k, 3 * f:3 * f + 3] if c[f] else QJ_NOM[:3]
+                if c[f]:
+                    ur[k, 3 * f + 2] = 8.912 * 9.81 / nc
+        refs = dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc)
+        phases.append(hkd_phase(h, dt, t0[i], c, nxt, refs))
+    return phases
+
+
+def hkd_ensemble_x0(batch, seed, phases):
+    """Perturbed copies of the first reference state (body pose / twist noise; qdummy kept consistent with the contact set)."""
+    g = SplitMix64(seed)
+    x0 = np.tile(phases[0]["bufs"]["xr"][0], (batch, 1))
+    for b in range(batch):
+        for i in range(12):
+            x0[b, i] += (g.next() - 0.5) * (0.06 if i < 6 else 0.2)
+    return x0
+
+
+def hkd_ddp_setting(**kw):
+    """HKDMPC/settings/ddp_setting.info as loadHSDDPSetting reads it (update_regularization stays 2: quirk xiii)."""
+    from ._abi import mhpc_ddp_setting
+    base = dict(alpha=0.1, gamma=0.01, update_penalty=5, update_relax=1, update_ReB=1, max_DDP_iter=10, max_AL_iter=5,
+                cost_thresh=1e-3, tconstr_thresh=1e-3, pconstr_thresh=1e-3, dynamics_feas_thresh=1e-3, merit_scale=0.2, merit_offset=1e2,
                 AL_active=1, ReB_active=1, MS=1)
     base.update(kw)
     return mhpc_ddp_setting(**base)

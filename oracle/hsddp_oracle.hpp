@@ -24,6 +24,7 @@
 #include "linalg.hpp"
 #include "wbm.hpp"
 #include "srbm.hpp"
+#include "hkdm.hpp"
 
 namespace orc {
 
@@ -119,6 +120,19 @@ struct Solver {
             }
         } else if (P.d.model == HSDDP_MODEL_SRB) {
             if (d.c_minheight) { int f = P.cons.size(); P.cons.push_back({0, 1, {2, 0, 0}, {1, 0, 0}, -d.h_min}); add_group(f, d.reb_minheight); }
+        } else if (P.d.model == HSDDP_MODEL_HKD) {
+            bool any = false; for (int l = 0; l < 4; l++) any |= d.contact[l] == 1;
+            if (d.c_grf && any) {   // GRFConstraint on u[0:12] (HKDConstraints.cpp:7-63), legs FR FL HR HL
+                int f = P.cons.size(); double mu = d.mu;
+                for (int l = 0; l < 4; l++) if (d.contact[l] > 0) {
+                    P.cons.push_back({1, 1, {3 * l + 2, 0, 0}, {1, 0, 0}, 0});
+                    P.cons.push_back({1, 2, {3 * l, 3 * l + 2, 0}, {-1, mu, 0}, 0});
+                    P.cons.push_back({1, 2, {3 * l, 3 * l + 2, 0}, {1, mu, 0}, 0});
+                    P.cons.push_back({1, 2, {3 * l + 1, 3 * l + 2, 0}, {-1, mu, 0}, 0});
+                    P.cons.push_back({1, 2, {3 * l + 1, 3 * l + 2, 0}, {1, mu, 0}, 0});
+                }
+                add_group(f, d.reb_grf);
+            }
         }
         P.n_td = 0; P.has_impact = false;
         for (int l = 0; l < 4; l++) { P.td[l] = (d.contact[l] == 0 && d.next_contact[l] == 1) ? 1 : 0; P.n_td += P.td[l]; }
@@ -132,7 +146,6 @@ struct Solver {
         for (int i = 0; i < n_phases; i++) {
             PhaseDef& P = ph[i]; P.d = phases[i];
             model_dims(P.d.model, P.n, P.m, P.p); P.h = P.d.horizon;
-            if (P.d.model == HSDDP_MODEL_HKD) return HSDDP_ENOTSUP;
             int h1 = P.h + 1;
             auto cp = [&](const double* src, int w, std::vector<double>& dst) { dst.assign((size_t)h1 * w, 0.0); if (src && w) std::memcpy(dst.data(), src, sizeof(double) * h1 * w); };
             cp(P.d.xr, P.n, P.xr); cp(P.d.ur, P.m, P.ur); cp(P.d.yr, P.p, P.yr);
@@ -165,7 +178,7 @@ struct Solver {
         for (const auto& gr : P.groups) for (int k = 0; k < h; k++) for (int i = 0; i < gr.size; i++) {
             T.delta[(size_t)k * ng + gr.first + i] = gr.init.delta; T.eps[(size_t)k * ng + gr.first + i] = gr.init.eps;
         }
-        int nt = (P.d.c_touchdown && P.d.model == HSDDP_MODEL_WB) ? P.n_td : 0;
+        int nt = (P.d.c_touchdown && P.d.model != HSDDP_MODEL_SRB) ? P.n_td : 0;
         z(T.th, nt); z(T.thx, (size_t)nt * n); T.sigma.assign(nt, P.d.al_td.sigma); T.lambda.assign(nt, P.d.al_td.lambda);
         T.max_pviol = T.max_tviol = 0; std::memset(T.x_init, 0, sizeof(T.x_init)); std::memset(T.dx_init, 0, sizeof(T.dx_init));
         T.dV_1 = T.dV_2 = T.actual_cost = 0; T.shooting = P.d.shooting != 0;
@@ -174,14 +187,17 @@ struct Solver {
     // ------------------------------------------------------------------ models
     void dynamics(const PhaseDef& P, int k, const double* x, const double* u, double* xnext, double* y) const {
         if (P.d.model == HSDDP_MODEL_WB) { WbParams w = wp; w.bg_alpha = P.d.BG_alpha; wb_dynamics(w, x, u, P.d.contact, P.d.dt, xnext, y); }
+        else if (P.d.model == HSDDP_MODEL_HKD) hkd_dynamics(x, u, P.d.contact, P.d.dt, xnext);
         else srb_dynamics(x, u, &P.foot_pos[(size_t)k * 12], &P.ref_contact[(size_t)k * 4], P.d.dt, xnext);
     }
     void dynamics_partial(const PhaseDef& P, int k, const double* x, const double* u, double* A, double* B, double* C, double* D) const {
         if (P.d.model == HSDDP_MODEL_WB) { WbParams w = wp; w.bg_alpha = P.d.BG_alpha; wb_dynamics_partial(w, x, u, P.d.contact, P.d.dt, A, B, C, D); }
+        else if (P.d.model == HSDDP_MODEL_HKD) hkd_dynamics_partial(x, u, P.d.contact, P.d.dt, A, B);
         else srb_dynamics_partial(x, u, &P.foot_pos[(size_t)k * 12], &P.ref_contact[(size_t)k * 4], P.d.dt, A, B);
     }
     // MHPCReset::reset_map (MHPCReset.cpp:4-28); returns dim of xnext
     int resetmap(const PhaseDef& P, const double* x, double* xnext) const {
+        if (P.d.model == HSDDP_MODEL_HKD) { hkd_resetmap(x, P.d.contact, P.d.next_contact, wp.psi_kin, xnext); return 24; }   // HKDReset.h:41-76
         double tmp[36];
         if (P.d.model == HSDDP_MODEL_WB && P.has_impact) wb_impact(wp, x, P.d.contact, P.d.next_contact, tmp);
         else std::memcpy(tmp, x, sizeof(double) * P.n);
@@ -194,6 +210,7 @@ struct Solver {
     }
     // Px: n_next x n column-major (MHPCReset.cpp:31-52)
     int resetmap_partial(const PhaseDef& P, const double* x, double* Px) const {
+        if (P.d.model == HSDDP_MODEL_HKD) { hkd_resetmap_partial(x, P.d.contact, P.d.next_contact, wp.psi_kin, Px); return 24; }   // HKDReset.h:78-136
         int n = P.n;
         std::vector<double> full((size_t)n * n, 0.0);
         if (P.d.model == HSDDP_MODEL_WB && P.has_impact) wb_impact_partial(wp, x, P.d.contact, P.d.next_contact, full.data());
@@ -224,6 +241,14 @@ struct Solver {
     void terminal_constraints(const PhaseDef& P, Traj& T) const {
         int nt = T.th.size(); T.max_tviol = 0;
         if (!nt) return;
+        if (P.d.model == HSDDP_MODEL_HKD) {   // TouchDownConstraint::compute_violation (HKDConstraints.cpp:75-111)
+            const double* x = &T.X[(size_t)P.h * P.n]; int i = 0;
+            for (int l = 0; l < 4; l++) if (P.td[l]) {
+                double pf[3], J[3][9]; hkd_foot_jac(x + 3, x, x + 12 + 3 * l, l, wp.psi_kin, pf, J);
+                T.th[i] = pf[2] - P.d.ground_height; T.max_tviol = std::max(T.max_tviol, std::fabs(T.th[i])); i++;
+            }
+            return;
+        }
         WbFootKin F; WbParams w = wp; wb_foot_kin(w, &T.X[(size_t)P.h * P.n], F, false);
         int i = 0;
         for (int l = 0; l < 4; l++) if (P.td[l]) { T.th[i] = F.pos[l][2] - P.d.ground_height; T.max_tviol = std::max(T.max_tviol, std::fabs(T.th[i])); i++; }
@@ -255,6 +280,11 @@ struct Solver {
                 if (rc[f] == 0 && P.d.w_swing_vel[0] >= 0) { double s = 0; for (int a = 0; a < 3; a++) { double dv = F->vel[f][a] - P.foot_vel[(size_t)k * 12 + 3 * f + a]; s += dv * P.d.w_swing_vel[a] * dv; } l4 += 0.5 * s * dt; }
             }
             l += l2; l += l3; l += l4;
+        } else if (P.d.model == HSDDP_MODEL_HKD && P.d.w_foot_reg[0] >= 0) {   // HKDFootPlaceReg::running_cost (HKDCost.cpp:4-19): Qfoot = diag(c_l * w)
+            const double* fp = &P.foot_pos[(size_t)k * 12]; const double* bp = &P.body_pos[(size_t)k * 3];
+            double s = 0;
+            for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) { double d = (x[12 + 3 * f + a] - x[3 + a]) - (fp[3 * f + a] - bp[a]); s += d * (P.d.contact[f] * P.d.w_foot_reg[a]) * d; }
+            double t = .5 * s; t *= dt; l += t;
         }
         T.l[k] = l;
     }
@@ -287,6 +317,11 @@ struct Solver {
                 if (P.td[f] && P.n_td > 0 && P.d.w_td_vel >= 0) { double vz = F->vel[f][2]; l5 += 0.5 * vz * P.d.w_td_vel * vz; }  // TDVelocityPenalty (MHPCCost.cpp:255-268)
             }
             Phi += l2; Phi += l5;
+        } else if (P.d.model == HSDDP_MODEL_HKD && P.d.w_foot_reg[0] >= 0) {   // HKDFootPlaceReg::terminal_cost (HKDCost.cpp:37-49): 10 d'Qd
+            const double* fp = &P.foot_pos[(size_t)h * 12]; const double* bp = &P.body_pos[(size_t)h * 3];
+            double s = 0;
+            for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) { double d = (x[12 + 3 * f + a] - x[3 + a]) - (fp[3 * f + a] - bp[a]); s += d * (P.d.contact[f] * P.d.w_foot_reg[a]) * d; }
+            Phi += 10 * s;
         }
         T.Phi = Phi;
     }
@@ -344,6 +379,7 @@ struct Solver {
                 for (int i = 0; i < n * n; i++) lxx[i] += txx[i];
             }
         }
+        if (P.d.model == HSDDP_MODEL_HKD && P.d.w_foot_reg[0] >= 0) hkd_footreg_par(P, x, &P.foot_pos[(size_t)k * 12], &P.body_pos[(size_t)k * 3], dt, lx, lxx);
         if (opt.ReB_active) {  // compute_ReB_partials (ConstraintsBase.h:250-289) + SinglePhase.cpp:404-418
             int ng = P.cons.size();
             for (const auto& gr : P.groups) {
@@ -367,9 +403,40 @@ struct Solver {
             }
         }
     }
+    // HKDFootPlaceReg::running_cost_par / terminal_cost_par (HKDCost.cpp:22-35, 52-65): scale * dprel_dx' Qfoot (d | dprel_dx),
+    // dprel_dx row (f,a) = contact_f * (e_{12+3f+a} - e_{3+a})
+    void hkd_footreg_par(const PhaseDef& P, const double* x, const double* fp, const double* bp, double scale, double* gx, double* gxx) const {
+        const int n = 24;
+        for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) {
+            const double cf = P.d.contact[f], q = cf * P.d.w_foot_reg[a];
+            const double d = (x[12 + 3 * f + a] - x[3 + a]) - (fp[3 * f + a] - bp[a]);
+            const int i0 = 12 + 3 * f + a, i1 = 3 + a;
+            gx[i0] += scale * cf * q * d; gx[i1] -= scale * cf * q * d;
+            gxx[i0 + n * i0] += scale * cf * q * cf; gxx[i1 + n * i1] += scale * cf * q * cf;
+            gxx[i0 + n * i1] -= scale * cf * q * cf; gxx[i1 + n * i0] -= scale * cf * q * cf;
+        }
+    }
     void terminal_cost_par(const PhaseDef& P, Traj& T, const hsddp_option_t& opt) const {
         int n = P.n, h = P.h; const double* x = &T.X[(size_t)h * n];
         for (int i = 0; i < n; i++) { T.Phix[i] += P.d.qf[i] * (x[i] - P.xr[(size_t)h * n + i]); T.Phixx[i + n * i] += P.d.qf[i]; }
+        if (P.d.model == HSDDP_MODEL_HKD) {
+            if (P.d.w_foot_reg[0] >= 0) hkd_footreg_par(P, x, &P.foot_pos[(size_t)h * 12], &P.body_pos[(size_t)h * 3], 20.0, T.Phix.data(), T.Phixx.data());
+            if (opt.AL_active && !T.th.empty()) {   // TouchDownConstraint::compute_partial (HKDConstraints.cpp:113-170) + compute_AL_partials
+                int i = 0; std::vector<double> ag(n, 0.0), ah((size_t)n * n, 0.0);
+                for (int l = 0; l < 4; l++) if (P.td[l]) {
+                    double J[3][9]; hkd_foot_jac(x + 3, x, x + 12 + 3 * l, l, wp.psi_kin, nullptr, J);
+                    double* hx = &T.thx[(size_t)i * n]; std::fill_n(hx, n, 0.0);
+                    for (int j = 0; j < 3; j++) { hx[j] = J[2][3 + j]; hx[3 + j] = J[2][j]; hx[12 + 3 * l + j] = J[2][6 + j]; }
+                    double sg = T.sigma[i], lm = T.lambda[i], hh = T.th[i];
+                    for (int a = 0; a < n; a++) ag[a] += (sg * hh + lm) * hx[a];
+                    for (int b = 0; b < n; b++) for (int a = 0; a < n; a++) ah[a + n * b] += (sg * (1 + hh) + lm) * (hx[a] * hx[b]);
+                    i++;
+                }
+                for (int a = 0; a < n; a++) T.Phix[a] += ag[a];
+                for (int a = 0; a < n * n; a++) T.Phixx[a] += ah[a];
+            }
+            return;
+        }
         if (P.d.model != HSDDP_MODEL_WB) return;
         WbFootKin F; wb_foot_kin(wp, x, F, true);
         const int* rc = &P.ref_contact[(size_t)h * 4]; const double* fp = &P.foot_pos[(size_t)h * 12]; const double* bp = &P.body_pos[(size_t)h * 3];

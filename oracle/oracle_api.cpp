@@ -172,4 +172,18 @@ void oracle_srb_xdot(const double* x, const double* u, const double* pf, const i
     if (Ac && Bc) srb_partials_ct(x, u, pf, c, Ac, Bc);
 }
 
+// HKD model probes (tests/test_oracle_models.py): Euler step + partials; leg kinematics; reset map + partial
+void oracle_hkd_step(const double* x, const double* u, double dt, const int* c, double* xn, double* A, double* B) {
+    hkd_dynamics(x, u, c, dt, xn);
+    if (A && B) hkd_dynamics_partial(x, u, c, dt, A, B);
+}
+void oracle_hkd_foot(const double* pos, const double* eul, const double* ql, int leg, double psi, double* pf, double* J27) {
+    double J[3][9]; hkd_foot_jac(pos, eul, ql, leg, psi, pf, J);
+    for (int a = 0; a < 3; a++) for (int j = 0; j < 9; j++) J27[a * 9 + j] = J[a][j];
+}
+void oracle_hkd_reset(const double* x, const int* c, const int* cn, double psi, double* xn, double* Px) {
+    hkd_resetmap(x, c, cn, psi, xn);
+    if (Px) hkd_resetmap_partial(x, c, cn, psi, Px);
+}
+
 }  // extern "C"

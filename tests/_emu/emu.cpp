@@ -14,6 +14,7 @@
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
 #include "srb_knot.hpp"
+#include "hkd_knot.hpp"
 #include "sweep.hpp"
 
 using namespace hs;
@@ -41,7 +42,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI; h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
     h->ph.resize(n_phases); HostMem mem{h};
     for (int i = 0; i < n_phases; i++) {
-        if (phases[i].model == HSDDP_MODEL_HKD || (i > 0 && phases[i].model == HSDDP_MODEL_WB && phases[i - 1].model != HSDDP_MODEL_WB)) return HSDDP_ENOTSUP;
+        if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) return HSDDP_ENOTSUP;
         int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, batch, h->ph[i], (int)h->sp.size());
         if (rc) return rc;
         for (int k = 0; k <= phases[i].horizon; k++) { h->sp.push_back(i); h->sk.push_back(k); }
@@ -65,13 +66,16 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
 static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
 int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
     OptDev o = to_dev(*opt); SlotOut so{h->cost.data(), h->dsq.data(), h->ming.data(), h->maxh.data()};
-    static WbCore L; static SrbLds Ls;
+    static WbCore L; static SrbLds Ls; static HkdLds Lh;
     for (int b = 0; b < h->batch; b++) {
         h->fail[b] = 0;
         for (int s = 0; s < h->nslots; s++) {
             int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi]; size_t slot = (size_t)b * h->nslots + s;
             const PhaseDev* Pn = pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr;
-            if (P.model == HSDDP_MODEL_SRB) {
+            if (P.model == HSDDP_MODEL_HKD) {
+                if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+                else hkd_rollout_terminal<64>(Lh, P, Pn, h->md, b, eps, o.AL_active, so, slot);
+            } else if (P.model == HSDDP_MODEL_SRB) {
                 if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
                 else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot);
             } else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
@@ -84,10 +88,11 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
 }
 int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }
 int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
-    OptDev o = to_dev(*opt); static WbLqLds L; static SrbLds Ls;
+    OptDev o = to_dev(*opt); static WbLqLds L; static SrbLds Ls; static HkdLds Lh;
     for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
         int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
-        if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
+        if (P.model == HSDDP_MODEL_HKD) { if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, o.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active); }
+        else if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
         else if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
         else wb_lq_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
     }
@@ -95,12 +100,12 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
 }
 int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
     static SweepLds S;
-    for (int b = 0; b < h->batch; b++) { bool ok = riccati_sweep<SW_NT>(S, h->ph.data(), h->nph, b, reg); if (success) success[b] = ok; h->dV1[b] = S.dV1; h->dV2[b] = S.dV2; }
+    for (int b = 0; b < h->batch; b++) { bool ok = riccati_sweep<SW_NT>(S, h->ph.data(), h->nph, b, reg); if (success) success[b] = ok; h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
     return 0;
 }
 int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t*) {
     static SweepLds S;
-    for (int b = 0; b < h->batch; b++) { linear_rollout<SW_NT>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.dV1; h->dV2[b] = S.dV2; }
+    for (int b = 0; b < h->batch; b++) { linear_rollout<SW_NT>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
     return 0;
 }
 int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {

@@ -42,7 +42,7 @@ def _srb_x0(x0):
     return np.ascontiguousarray(x0[:, list(range(6)) + list(range(18, 24))])     # StateProjection (MHPCReset.h:24-26)
 
 
-@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll"])
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll", "hkd"])
 def test_per_iterate_parity(hip_lib, oracle_lib, which):
     x0 = pkg.problems.wb_ensemble_x0(3, 20241222)
     if which == "barrel_roll":   # BarrelRollTO.cpp at short phase durations; conditioning note in test_kernel_logic_emu.py
@@ -52,6 +52,12 @@ def test_per_iterate_parity(hip_lib, oracle_lib, which):
         # gains reach |K| ~ 250 on this iterate: K is held to 1e-7 RELATIVE here (2.5e-5 absolute at that scale), every other
         # case in this file keeps north_star's 1e-6 absolute bound
         pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, rtol=1e-7, atol_K=None)
+        return
+    if which == "hkd":         # HKD-MPC trot (24/24/0): kinodynamic phases with lift-off / touchdown reset maps
+        phases = pkg.problems.hkd_trot_problem(horizons=(6, 7, 6, 5))
+        x0 = pkg.problems.hkd_ensemble_x0(3, 11, phases)
+        so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+        pc.run_steps(pkg, so, sg, phases, pkg.problems.hkd_ddp_setting(), n_iter=3)
         return
     if which == "mhpc":        # whole-body phases + single-rigid-body tail (state dimension 36 -> 12 across the impact reset)
         phases = pkg.problems.mhpc_problem(wb_horizons=(7, 6), srb_horizons=(5, 4))
@@ -83,6 +89,17 @@ def test_full_solve_parity_mhpc(hip_lib, oracle_lib):
     so.solve(opt); sg.solve(opt)
     pc.compare_solve(so, sg, len(phases))
     assert (sg.info_arrays()["n_iters"] >= 2).all()
+
+
+def test_full_solve_parity_hkd(hip_lib, oracle_lib):
+    """BASELINE config 4 in shape: HKD-MPC trot, 4 phases, HKDMPC/settings/ddp_setting.info, AL + ReB active, converge mode."""
+    phases = pkg.problems.hkd_trot_problem(horizons=(10, 10, 10, 10))
+    x0 = pkg.problems.hkd_ensemble_x0(6, 5, phases)
+    opt = pkg.problems.hkd_ddp_setting()
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
+    assert (sg.info_arrays()["n_iters"] > 3).all() and (sg.info_arrays()["max_tconstr"] < 1e-3).all()
 
 
 def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib):
@@ -196,6 +213,7 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     s.set_nominal(0, phases[0]["Xbar"], phases[0]["Ubar"]); s.set_initial_condition(pkg.problems.wb_nominal_state()[None])
     with pytest.raises(RuntimeError):
         s.solve(pkg.mhpc_ddp_setting(MS=0))              # single shooting: HSDDP_ENOTSUP, never a silent fallback
-    phases[0]["desc"].model = pkg.MODEL_HKD
+    mixed = pkg.problems.mhpc_problem(wb_horizons=(3, 3), srb_horizons=(2, 2))
+    mixed[-1]["desc"].model = pkg.MODEL_HKD          # SRB -> HKD: the reference has no such reset map
     with pytest.raises(RuntimeError):
-        pkg.Solver(hip_lib, phases, batch=1)
+        pkg.Solver(hip_lib, mixed, batch=1)

@@ -19,7 +19,7 @@ def emu_lib():
     return pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu.so")))
 
 
-@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll"])
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll", "hkd"])
 def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
     if which == "mhpc":    # whole-body phases + single-rigid-body tail: mixed state dimension across the phase boundary
         phases = pkg.problems.mhpc_problem(wb_horizons=(4, 3), srb_horizons=(3, 2))
@@ -34,6 +34,10 @@ def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
         phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.03, 0.06, 0.10, 0.13, 0.16, 0.19))
         x0 = np.vstack([xinit, xinit + 0.01 * (x0[0] - pkg.problems.wb_nominal_state())])
         opt = pkg.problems.br_ddp_setting()
+    if which == "hkd":           # HKD-MPC trot: 24/24/0 phases, lift-off / touchdown reset maps, touchdown constraint from leg kinematics
+        phases = pkg.problems.hkd_trot_problem(horizons=(3, 4, 3, 3))
+        x0 = pkg.problems.hkd_ensemble_x0(2, 11, phases)
+        opt = pkg.problems.hkd_ddp_setting()
     so, se = pc.make_pair(pkg, oracle_lib, emu_lib, phases, x0)
     # the barrel-roll iterate after a full step from the zero-torque start is badly conditioned (cond(Quu) ~ 1e6): Cholesky here vs
     # pivoted LDLT in the oracle differ by ~1e-8 relative in dU; K stays inside the 1e-6 absolute bound of north_star
