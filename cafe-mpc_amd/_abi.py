@@ -85,7 +85,7 @@ EXPORTS = ["hsddp_create", "hsddp_destroy", "hsddp_set_initial_condition", "hsdd
            "hsddp_hybrid_rollout", "hsddp_compute_cost", "hsddp_LQ_approximation", "hsddp_backward_sweep",
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
-           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_backend_name"]
+           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_export_mpc_command", "hsddp_backend_name"]
 
 
 def bind(lib):
@@ -112,6 +112,7 @@ def bind(lib):
     lib.hsddp_get_solve_time_ms.argtypes = [H]
     lib.hsddp_get_solve_time_ms.restype = C.c_float
     lib.hsddp_get_kernel_times.argtypes = [H, C.c_int, DP, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
+    lib.hsddp_export_mpc_command.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     lib.hsddp_backend_name.argtypes = []
     lib.hsddp_backend_name.restype = C.c_char_p
     return lib
@@ -228,6 +229,28 @@ class Solver:
 
     def solve_time_ms(self):
         return float(self.lib.hsddp_get_solve_time_ms(self.h))
+
+    CMD_FIELDS = (("mpc_times", 1, "f"), ("torque", 12, "f"), ("eul", 3, "f"), ("pos", 3, "f"), ("qJ", 12, "f"), ("vWorld", 3, "f"),
+                  ("eulrate", 3, "f"), ("qJd", 12, "f"), ("GRF", 12, "f"), ("feedback", 432, "f"), ("Qu", 12, "f"), ("Quu", 144, "f"),
+                  ("Qux", 432, "f"), ("contacts", 4, "i"), ("statusTimes", 4, "f"))
+
+    def export_mpc_command(self, problem=0, n_steps=8, mpc_time=0.0, dt=0.01, status_times=None):
+        """MHPC_Command_lcmt content (MHPCLocomotion.cpp:190-287) of one problem as a dict of fp32/int32 arrays + the raw words."""
+        words = np.zeros(1 + n_steps * 1089, dtype=np.uint32)
+        st = None
+        if status_times is not None:
+            st = np.ascontiguousarray(status_times, dtype=np.float32); assert st.shape == (len(self.phases), 4)
+        rc = self.lib.hsddp_export_mpc_command(self.h, problem, n_steps, float(mpc_time), float(dt),
+                                               st.ctypes.data_as(C.POINTER(C.c_float)) if st is not None else None,
+                                               words.ctypes.data_as(C.POINTER(C.c_uint)))
+        if rc != 0:
+            raise RuntimeError(f"hsddp_export_mpc_command failed: {rc}")
+        out = {"N_mpcsteps": int(words[0].view(np.int32)), "raw": words}
+        pos = 1
+        for name, w, kind in self.CMD_FIELDS:
+            seg = words[pos:pos + n_steps * w]; pos += n_steps * w
+            out[name] = seg.view(np.float32 if kind == "f" else np.int32).reshape(n_steps, w).copy()
+        return out
 
     def kernel_times(self, max_n=32):
         ms = np.zeros(max_n)

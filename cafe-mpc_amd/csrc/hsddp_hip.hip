@@ -153,6 +153,41 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph, i
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
 }
 
+// MHPC_Command_lcmt packing (include/hsddp.h): one workgroup per control step, fp64 -> fp32 on the device
+__global__ void __launch_bounds__(256) k_pack_command(const PhaseDev* ph, const int* step_phase, const int* step_k, int n_steps, int b, double t0, double dt,
+                                                     const float* status, unsigned int* out) {
+    const int s = blockIdx.x; const PhaseDev& P = ph[step_phase[s]]; const int k = step_k[s];
+    const double* X = P.Xbar + ((size_t)b * (P.h + 1) + k) * 36; const size_t kk = (size_t)b * P.h + k;
+    constexpr int NF = 15; const int wd[NF] = {1, 12, 3, 3, 12, 3, 3, 12, 12, 432, 12, 144, 432, 4, 4};
+    if (s == 0 && threadIdx.x == 0) out[0] = (unsigned int)n_steps;
+    size_t off = 1;
+    for (int f = 0; f < NF; f++) {
+        unsigned int* dst = out + off + (size_t)s * wd[f];
+        for (int e = threadIdx.x; e < wd[f]; e += blockDim.x) {
+            float v = 0.f; bool is_int = false; int iv = 0;
+            switch (f) {
+                case 0: v = (float)(t0 + s * dt); break;
+                case 1: v = (float)P.Ubar[kk * 12 + e]; break;
+                case 2: v = (float)X[3 + e]; break;
+                case 3: v = (float)X[e]; break;
+                case 4: v = (float)X[6 + e]; break;
+                case 5: v = (float)X[18 + e]; break;
+                case 6: v = (float)X[21 + e]; break;
+                case 7: v = (float)X[24 + e]; break;
+                case 8: v = (float)P.Y[kk * 12 + e]; break;
+                case 9: v = (float)P.K[kk * 432 + e]; break;
+                case 10: v = (float)P.Qu[kk * 12 + e]; break;
+                case 11: v = (float)P.Quu[kk * 144 + e]; break;
+                case 12: v = (float)P.Qux[kk * 432 + e]; break;
+                case 13: is_int = true; iv = P.contact[e]; break;
+                default: v = status ? status[step_phase[s] * 4 + e] : 0.f; break;
+            }
+            dst[e] = is_int ? (unsigned int)iv : __float_as_uint(v);
+        }
+        off += (size_t)n_steps * wd[f];
+    }
+}
+
 // X -> Xbar, U -> Ubar, Defect -> Defect_bar (Trajectory::update_nominal_vals, TrajectoryManagement.cpp:122-127)
 __global__ void k_update_nominal(const PhaseDev* ph, int nph, const ProbState* st, int mask) {
     const int b = blockIdx.y;
@@ -581,6 +616,27 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     return HSDDP_OK;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h ? h->solve_ms : 0.f; }
+
+int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double mpc_time, double dt, const float* status_times, unsigned int* out) {
+    if (!h || problem < 0 || problem >= h->batch || n_steps <= 0 || !out) return HSDDP_EINVAL;
+    std::vector<int> sp, sk;   // control knot k -> (phase, k_rel)   (MHPCProblemData::get_index)
+    for (int i = 0; i < h->nph && (int)sp.size() < n_steps; i++) {
+        if (h->ph[i].model != HSDDP_MODEL_WB) break;
+        for (int k = 0; k < h->ph[i].h && (int)sp.size() < n_steps; k++) { sp.push_back(i); sk.push_back(k); }
+    }
+    if ((int)sp.size() < n_steps) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    const size_t words = 1 + (size_t)n_steps * HSDDP_CMD_WORDS_PER_STEP;
+    unsigned int* d_out = nullptr; int* d_map = nullptr; float* d_status = nullptr;
+    HIPCK(hipMalloc(&d_out, words * 4)); HIPCK(hipMalloc(&d_map, 2 * n_steps * sizeof(int)));
+    HIPCK(hipMemcpy(d_map, sp.data(), n_steps * sizeof(int), hipMemcpyHostToDevice)); HIPCK(hipMemcpy(d_map + n_steps, sk.data(), n_steps * sizeof(int), hipMemcpyHostToDevice));
+    if (status_times) { HIPCK(hipMalloc(&d_status, h->nph * 4 * sizeof(float))); HIPCK(hipMemcpy(d_status, status_times, h->nph * 4 * sizeof(float), hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_pack_command, dim3(n_steps), dim3(256), 0, h->stream, h->d_ph, d_map, d_map + n_steps, n_steps, problem, mpc_time, dt, d_status, d_out);
+    HIPCK(hipStreamSynchronize(h->stream));
+    HIPCK(hipMemcpy(out, d_out, words * 4, hipMemcpyDeviceToHost));
+    hipFree(d_out); hipFree(d_map); if (d_status) hipFree(d_status);
+    return HSDDP_OK;
+}
 
 int hsddp_get_kernel_times(hsddp_handle_t* h, int max_n, double* ms, long long* launches, char* names, int names_cap) {
     if (!h) return 0;

@@ -241,7 +241,9 @@ HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, do
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
     chol_s<NT, 18, 18>(L.M, D.Lm(), L.rdM, 0.0);
+    LQ_STAMP(7)
     HS_PHASE(NT, if (tid < 18) inv_col_s<18, 18>(D.Lm(), L.rdM, D.Minv, 18, tid);)
+    LQ_STAMP(8)
     HS_PHASE(NT, if (tid < 18) {
         double s = 0;
         if (mode == 0) { _Pragma("unroll") for (int j = 0; j < 18; j++) s += D.Minv[tid * 18 + j] * (L.tau[j] - L.h[j]); } else s = L.x[18 + tid];
@@ -264,7 +266,9 @@ HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, do
         for (int i = 0; i < 18; i++) s += L.Jc()[tid * 18 + i] * L.a0[i];
         L.rhs[tid] = (tid < m) ? (-s - L.gam[tid]) : 0.0;
     })
+    LQ_STAMP(9)
     chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    LQ_STAMP(10)
     HS_PHASE(NT, if (tid == 0) {
         double lam[12];
         _Pragma("unroll")
@@ -274,9 +278,11 @@ HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, do
         for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
     })
     HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[tid * 12 + a] * L.lam[a]; L.qdd[tid] = s; })
+    LQ_STAMP(11)
     // the KKT inverse reuses the factor of the forward solve: Pinocchio's computeKKTContactDynamicMatrixInverse uses damping 0,
     // forwardDynamics 1e-12; keeping one factor changes Lambda by <= 1e-12 * cond(J Minv J^T) relative (1e-11 here).
     HS_PHASE(NT, if (tid < 12) inv_col_s<12, 12>(L.LG(), L.rdG, D.Lam(), 12, tid);)
+    LQ_STAMP(12)
     HS_PHASE(NT, if (tid < 12) {             // Y = X Lam with padded rows/cols of Lam forced to zero
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) { double s = 0; _Pragma("unroll") for (int b = 0; b < 12; b++) s += L.Xm()[i * 12 + b] * D.Lam()[b * 12 + tid]; D.Ym()[i * 12 + tid] = (tid < m) ? s : 0.0; }
@@ -461,7 +467,7 @@ HD void wb_rollout_terminal(WbCore& L, const PhaseDev& P, const PhaseDev* Pn, co
 
 // -------------------------------------------------------------------------------------------------------
 // coalesced copy LDS -> global
-template <int NT> HD void store_block(double* dst, const double* src, int n) { HS_PHASE(NT, for (int i = tid; i < n; i += NT) dst[i] = src[i];) }
+template <int NT> HD void store_block(double* dst, const double* src, int n) { HS_PHASE_L(NT, for (int i = tid; i < n; i += NT) dst[i] = src[i];) }
 
 // foot-cost Jacobian blocks of the knot: JP (position-type rows, base-translation and velocity columns zero),
 // JW (velocity-type rows [d vel/dq | J]), with per-row weights (dt folded in) and residuals.  `terminal` selects the
@@ -576,24 +582,24 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     })
     LQ_STAMP(3)
     // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) {
+    HS_PHASE_L(NT, for (int e = tid; e < 1296; e += NT) {
         const int r = e % 36, c = e / 36;
         P.A[kk * P.rs + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
     })
     store_block<NT>(P.C + kk * P.rs, L.Jc(), 432);
-    HS_PHASE(NT,
+    HS_PHASE_L(NT,
         for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
         for (int e = tid; e < 144; e += NT) { const int r = e % 12, j = e / 12, f = r / 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = 3 * t + r % 3;
             P.D[kk * P.rs + e] = (a >= 0) ? -D.Kinv[(18 + a) * 30 + 6 + j] : 0.0; })
     LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
-    HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
+    HS_PHASE_L(NT, for (int c = tid; c < P.ng; c += NT) {
         size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
         if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
         D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
     } for (int e = tid; e < 1296; e += NT) D.W[e] = 0.0;)
-    HS_PHASE(NT, if (tid < 36) {
+    HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
         double lxd = dt * P.q[d] * (L.x[d] - P.xr[(size_t)k * 36 + d]);
         double diag = dt * P.q[d];
@@ -611,11 +617,11 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         D.W[d * 36 + d] += diag;
         P.lx[kk * P.rs + d] = lxd;
     })
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * P.rs + e] = D.W[r * 36 + c]; })
+    HS_PHASE_L(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * P.rs + e] = D.W[r * 36 + c]; })
     LQ_STAMP(5)
     // lu, luu (diag + torque barrier), ly, lyy (grf barrier 3x3 blocks) staged in Cst (288 of 432)
-    HS_PHASE(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
-    HS_PHASE(NT, if (tid < 12) {
+    HS_PHASE_L(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
+    HS_PHASE_L(NT, if (tid < 12) {
         const int i = tid;
         double lu = dt * P.r[i] * (L.u[i] - P.ur[(size_t)k * 12 + i]), luu = dt * P.r[i];
         if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }

@@ -162,6 +162,20 @@ float hsddp_get_solve_time_ms(hsddp_handle_t *h);
  * and number of launches; names returned as a NUL-separated list. Optional for the CPU backend. */
 int hsddp_get_kernel_times(hsddp_handle_t *h, int max_n, double *ms, long long *launches, char *names, int names_cap);
 
+/* -- policy export in the field order of lcmtypes/MHPC_Command_lcmt.lcm, filled the way MHPCLocomotion::publish_mpc_cmd does
+ * (MHPC/MHPCLocomotion.cpp:190-287): the first n_steps control knots of problem `problem`, walking the whole-body phases in
+ * order, everything cast to fp32, matrices column-major (Eigen .data()).  `out` receives 32-bit words (host byte order; LCM's
+ * own wire encoding is big-endian and adds a fingerprint — that stays with the caller's lcm-gen code):
+ *   [0]                       int32  N_mpcsteps
+ *   then, each as N_mpcsteps consecutive rows:  float mpc_times[1] | torque[12] (Ubar) | eul[3] (Xbar 3..5) | pos[3] (Xbar 0..2) |
+ *   qJ[12] (Xbar 6..17) | vWorld[3] (Xbar 18..20) | eulrate[3] (Xbar 21..23) | qJd[12] (Xbar 24..35) | GRF[12] (Y) |
+ *   feedback[432] (K 12x36) | Qu[12] | Quu[144] | Qux[432] | int32 contacts[4] (phase contact) | float statusTimes[4]
+ * mpc_times[k] = mpc_time + k*dt; status_times: n_phases x 4 (wb_contact_durations) or NULL (zeros).
+ * Fails with HSDDP_EINVAL if the first n_steps knots are not all whole-body knots. */
+#define HSDDP_CMD_WORDS_PER_STEP 1089
+int hsddp_export_mpc_command(hsddp_handle_t *h, int problem, int n_steps, double mpc_time, double dt, const float *status_times,
+                             unsigned int *out /* 1 + n_steps*HSDDP_CMD_WORDS_PER_STEP words */);
+
 const char *hsddp_backend_name(void); /* "hip-gfx950" or "cpu-oracle" */
 
 #ifdef __cplusplus

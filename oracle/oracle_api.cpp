@@ -123,6 +123,32 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h->s.solve_ms; }
+// MHPCLocomotion::publish_mpc_cmd (MHPC/MHPCLocomotion.cpp:190-287) restated: field order of MHPC_Command_lcmt.lcm, fp32 casts
+int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double mpc_time, double dt, const float* status_times, unsigned int* out) {
+    if (!h || problem < 0 || problem >= h->s.batch || n_steps <= 0 || !out) return HSDDP_EINVAL;
+    std::vector<std::pair<int, int>> idx;
+    for (int i = 0; i < (int)h->s.ph.size() && (int)idx.size() < n_steps; i++) {
+        if (h->s.ph[i].d.model != HSDDP_MODEL_WB) break;
+        for (int k = 0; k < h->s.ph[i].h && (int)idx.size() < n_steps; k++) idx.push_back({i, k});
+    }
+    if ((int)idx.size() < n_steps) return HSDDP_EINVAL;
+    auto putf = [](unsigned int* p, double v) { float f = (float)v; std::memcpy(p, &f, 4); };
+    out[0] = (unsigned int)n_steps; unsigned int* p = out + 1;
+    const Problem& pb = h->s.pb[problem];
+    auto rows = [&](int w, auto get) { for (int s = 0; s < n_steps; s++) for (int e = 0; e < w; e++) get(p++, s, e); };
+    rows(1, [&](unsigned int* q, int s, int) { putf(q, mpc_time + s * dt); });
+    rows(12, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Ubar[(size_t)idx[s].second * 12 + e]); });
+    const int xo[6] = {3, 0, 6, 18, 21, 24}, xw[6] = {3, 3, 12, 3, 3, 12};
+    for (int g = 0; g < 6; g++) rows(xw[g], [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Xbar[(size_t)idx[s].second * 36 + xo[g] + e]); });
+    rows(12, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Y[(size_t)idx[s].second * 12 + e]); });
+    rows(432, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].K[(size_t)idx[s].second * 432 + e]); });
+    rows(12, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Qu[(size_t)idx[s].second * 12 + e]); });
+    rows(144, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Quu[(size_t)idx[s].second * 144 + e]); });
+    rows(432, [&](unsigned int* q, int s, int e) { putf(q, pb.tr[idx[s].first].Qux[(size_t)idx[s].second * 432 + e]); });
+    rows(4, [&](unsigned int* q, int s, int e) { *q = (unsigned int)h->s.ph[idx[s].first].d.contact[e]; });
+    rows(4, [&](unsigned int* q, int s, int e) { float f = status_times ? status_times[idx[s].first * 4 + e] : 0.f; std::memcpy(q, &f, 4); });
+    return 0;
+}
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
 
 // ---------------------------------------------------------------- model-level probes (tests only)

@@ -124,5 +124,6 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
+int hsddp_export_mpc_command(hsddp_handle_t*, int, int, double, double, const float*, unsigned int*) { return HSDDP_ENOTSUP; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
 }

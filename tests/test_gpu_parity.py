@@ -206,6 +206,43 @@ def test_regularisation_retry_gpu(hip_lib, oracle_lib):
     assert np.array_equal(a["status"], b["status"])
 
 
+def test_mpc_command_export(hip_lib, oracle_lib):
+    """Policy export in MHPC_Command_lcmt field order (MHPCLocomotion.cpp:190-287): the device-side fp32 packing is bit-exact
+    against a numpy packing of the same solver's fp64 fields, and agrees with the oracle's export to fp32 rounding."""
+    phases = pkg.problems.wb_trot_problem(horizons=(5, 6, 5, 6))      # 8 steps span the first two phases
+    x0 = pkg.problems.wb_ensemble_x0(3, 20241225)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    st = np.arange(16, dtype=np.float32).reshape(4, 4) * 0.01
+    for b in (0, 2):
+        cg = sg.export_mpc_command(problem=b, n_steps=8, mpc_time=1.5, dt=0.01, status_times=st)
+        co = so.export_mpc_command(problem=b, n_steps=8, mpc_time=1.5, dt=0.01, status_times=st)
+        assert cg["N_mpcsteps"] == 8 and cg["raw"].size == 1 + 8 * 1089
+        idx = [(0, k) for k in range(5)] + [(1, k) for k in range(3)]
+        X = np.array([sg.field(i, "XBAR")[b, k] for i, k in idx]); U = np.array([sg.field(i, "UBAR")[b, k] for i, k in idx])
+        exp = {"torque": U, "eul": X[:, 3:6], "pos": X[:, 0:3], "qJ": X[:, 6:18], "vWorld": X[:, 18:21], "eulrate": X[:, 21:24], "qJd": X[:, 24:36],
+               "GRF": np.array([sg.field(i, "Y")[b, k] for i, k in idx]),
+               "feedback": np.array([sg.field(i, "K")[b, k].T.ravel() for i, k in idx]),        # column-major 12x36
+               "Qu": np.array([sg.field(i, "QU")[b, k] for i, k in idx]),
+               "Quu": np.array([sg.field(i, "QUU")[b, k].T.ravel() for i, k in idx]),
+               "Qux": np.array([sg.field(i, "QUX")[b, k].T.ravel() for i, k in idx]),
+               "mpc_times": (1.5 + 0.01 * np.arange(8))[:, None]}
+        for name, v in exp.items():
+            assert np.array_equal(cg[name], v.astype(np.float32)), name
+        assert np.array_equal(cg["contacts"], np.array([phases[i]["desc"].contact[:] for i, _ in idx], dtype=np.int32))
+        assert np.array_equal(cg["statusTimes"], st[[i for i, _ in idx]])
+        for name, _, kind in sg.CMD_FIELDS:
+            if kind == "f":
+                assert np.allclose(cg[name], co[name], rtol=2e-6, atol=2e-6), name
+            else:
+                assert np.array_equal(cg[name], co[name])
+    mixed = pkg.problems.mhpc_problem(wb_horizons=(3, 3), srb_horizons=(2, 2))
+    sm = pkg.Solver(hip_lib, mixed, batch=1)
+    with pytest.raises(RuntimeError):
+        sm.export_mpc_command(n_steps=8)           # only 6 whole-body control knots exist
+
+
 def test_unsupported_configurations_fail_loudly(hip_lib):
     import ctypes
     phases = pkg.problems.wb_stance_problem(horizon=3)
