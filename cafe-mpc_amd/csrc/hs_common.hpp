@@ -75,6 +75,42 @@ HD double hs_rsqrt(double x) { return 1.0 / std::sqrt(x); }
 HD double hs_rsqrt(double x) { return rsqrt(x); }
 #endif
 
+#ifndef HS_HOST_EMU
+// broadcast of lane `src` (compile-time constant after unrolling -> v_readlane_b32 x2 into an SGPR pair)
+HD double hs_readlane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Same factorisation as chol_s (identical sequence of FMAs per entry, bit-identical result) but right-looking with row i
+// of the matrix in the REGISTERS of lane i: the pivot and the column being eliminated travel by lane broadcast, so a
+// column costs a dependent chain of a few instructions instead of an LDS round trip plus a workgroup barrier.
+// Must be called with all 64 lanes active.  Lo may alias A.
+template <int N, int LD>
+HD void chol_r(const double* A, int sr, int sk, double* Lo, double* rd, double diag_add, int tid, int* ok = nullptr) {   // A(i,k) = A[i*sr + k*sk]
+    const int row = tid < N ? tid : N - 1;          // idle lanes mirror the last row (never written back)
+    double a[N];
+    _Pragma("unroll")
+    for (int k = 0; k < N; k++) a[k] = A[row * sr + k * sk];
+    double rown = 0.0;
+    _Pragma("unroll")
+    for (int j = 0; j < N; j++) {
+        double piv = hs_readlane(a[j], j) + diag_add;
+        if (ok != nullptr) { const bool good = piv > 0.0; if (!good && tid == j) *ok = 0; piv = good ? piv : 1.0; }   // not positive definite: flag, keep going on a dummy pivot
+        const double r = hs_rsqrt(piv);
+        const double lij = a[j] * r;
+        a[j] = lij;
+        rown = (tid == j) ? r : rown;
+        _Pragma("unroll")
+        for (int k = j + 1; k < N; k++) a[k] -= lij * hs_readlane(lij, k);
+    }
+    if (tid < N) {
+        rd[tid] = rown;
+        _Pragma("unroll")
+        for (int k = 0; k < N - 1; k++) if (k < tid) Lo[tid * LD + k] = a[k];
+    }
+}
+#endif
+
 template <class S> struct V3 { S x, y, z; };
 template <class S> HD V3<S> operator+(V3<S> a, V3<S> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 template <class S> HD V3<S> operator-(V3<S> a, V3<S> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

@@ -137,6 +137,10 @@ HD void mfma_tile(int lane, double* Cout, int ldc, const double* Cin, int ldcin,
 // ---- wave-level (wave 0) factorisation helpers, compile-time size, recurrences in registers -------------------
 template <int N, int LD>
 HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok) {
+#ifndef HS_HOST_EMU
+    HS_WPHASE(chol_r<N, LD>(A, 1, LD, Lo, rd, diag_add, tid, ok);)     // rows in registers, lane broadcasts (hs_common.hpp)
+    return;
+#endif
     _Pragma("unroll")
     for (int j = 0; j < N; j++) {
         HS_WPHASE(if (tid >= j && tid < N) {
@@ -295,8 +299,8 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         HS_WPHASE(if (tid <= N) {
             double y[M];
             _Pragma("unroll") for (int i = 0; i < M; i++) y[i] = (tid < N) ? CM(S.Qux, i, tid, LDM) : S.Qu[i];
-            _Pragma("unroll") for (int i = 0; i < M; i++) { double s = y[i]; _Pragma("unroll") for (int k2 = 0; k2 < i; k2++) s -= S.LQ[i * LDM + k2] * y[k2]; y[i] = s * S.rdQ[i]; HS_CBAR(); }
-            _Pragma("unroll") for (int i = M - 1; i >= 0; i--) { double s = y[i]; _Pragma("unroll") for (int k2 = i + 1; k2 < M; k2++) s -= S.LQ[k2 * LDM + i] * y[k2]; y[i] = s * S.rdQ[i]; HS_CBAR(); }
+            _Pragma("unroll") for (int i = 0; i < M; i++) { double s = y[i]; _Pragma("unroll") for (int k2 = 0; k2 < i; k2++) s -= S.LQ[i * LDM + k2] * y[k2]; y[i] = s * S.rdQ[i]; if (i % 3 == 2) HS_CBAR(); }
+            _Pragma("unroll") for (int i = M - 1; i >= 0; i--) { double s = y[i]; _Pragma("unroll") for (int k2 = i + 1; k2 < M; k2++) s -= S.LQ[k2 * LDM + i] * y[k2]; y[i] = s * S.rdQ[i]; if (i % 3 == 0) HS_CBAR(); }
             _Pragma("unroll") for (int i = 0; i < M; i++) { if (tid < N) CM(S.K, i, tid, LDM) = -y[i]; else S.dU[i] = -y[i]; }
         })
         SW_STAMP(4)

@@ -39,18 +39,18 @@ struct WbCore {
     unsigned long long tstamp;
 };
 struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (see accessors)
-    double Minv[18 * 18];              // M^-1 ; later the barrier derivative tables bd / bdd
-    double Kinv[30 * 30];              // KKT inverse (padded) ; later the foot-cost Jacobian blocks JP / JW (2 x 12 x 36)
-    double W[18 * 54 + 18 * 36];       // before the tangent pass: Lm, Ym, Lam ; then T[18][54] tangent columns + R[18][36] result rows ;
-                                       // finally a dense 36x36 staging tile for lxx / Phixx
+    double JPW[2 * 432];               // column solve: staging of C (432) | B rows 18..35 (216) | D (144) ; then the foot-cost Jacobian blocks JP | JW (2 x 12 x 36)
+    double W[18 * 54 + 18 * 36];       // T[18][54] tangent columns + R[18][36] result rows ; finally a dense 36x36 staging tile for lxx / Phixx
     double wp[12], wv[12], ep[12], ev[12];
-    HD double* Lm() { return W; }
-    HD double* Ym() { return W + 324; }
-    HD double* Lam() { return W + 540; }
-    HD double* JP() { return Kinv; }
-    HD double* JW() { return Kinv + 432; }
-    HD double* bd() { return Minv; }
-    HD double* bdd() { return Minv + MAXG; }
+    double LGs[144], rdGs[12];         // Schur factor of the contact solve, kept while GG holds the foot tangents
+    double bdt[2 * MAXG];              // barrier derivative tables
+    HD double* JP() { return JPW; }
+    HD double* JW() { return JPW + 432; }
+    HD double* stC() { return JPW; }
+    HD double* stB() { return JPW + 432; }
+    HD double* stD() { return JPW + 648; }
+    HD double* bd() { return bdt; }
+    HD double* bdd() { return bdt + MAXG; }
 };
 constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
@@ -82,6 +82,17 @@ HD void chol_s(const double* A, double* Lo, double* rd, double diag_add) {
         })
     }
 }
+template <int NT, int N, int LD>
+HD void chol_f(const double* A, double* Lo, double* rd, double diag_add) {
+#ifdef HS_HOST_EMU
+    chol_s<NT, N, LD>(A, Lo, rd, diag_add);
+#else
+    HS_PHASE(NT, chol_r<N, LD>(A, LD, 1, Lo, rd, diag_add, tid);)
+#endif
+}
+#ifndef HS_SOLVE_CBAR
+#define HS_SOLVE_CBAR 100    // rows of a triangular solve between two scheduling fences (100: none; 1 keeps every row's loads behind the previous row)
+#endif
 // x = L^-1 b (forward) in registers; b/x are private arrays
 template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, double* x) {
     _Pragma("unroll")
@@ -90,7 +101,7 @@ template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, doubl
         _Pragma("unroll")
         for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * x[k];
         x[i] = s * rd[i];
-        HS_CBAR();
+        if (i % HS_SOLVE_CBAR == HS_SOLVE_CBAR - 1) HS_CBAR();
     }
 }
 // x = L^-T b (backward) in registers
@@ -101,7 +112,7 @@ template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, doubl
         _Pragma("unroll")
         for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * x[k];
         x[i] = s * rd[i];
-        HS_CBAR();
+        if (i % HS_SOLVE_CBAR == 0) HS_CBAR();
     }
 }
 // column c of (L L^T)^-1 into Inv[:, c] (row-major ldi). Called by lane c.
@@ -166,26 +177,27 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
 // compile-time trip count (mode 0: gam = Jdot v + 2 alpha J v ; mode 1: 0)
 template <int NT>
 HD void wb_select(WbCore& L, int nc, const int* feet, int mode, double alpha) {
-    HS_PHASE(NT, if (tid < 12) {
-        const bool act = tid < 3 * nc;
-        const int f = act ? feet[tid / 3] : 0, r = tid % 3;
-        _Pragma("unroll")
-        for (int j = 0; j < 18; j++) L.Jc()[tid * 18 + j] = act ? L.Jall[(3 * f + r) * 18 + j] : 0.0;
-        L.gam[tid] = (act && mode == 0) ? (L.Jdv[3 * f + r] + 2.0 * alpha * L.fvel[3 * f + r]) : 0.0;
-        L.grf[tid] = 0.0;
-    })
+    HS_PHASE(NT,
+        for (int e = tid; e < 216; e += NT) {
+            const int a = e / 18, j = e % 18; const bool act = a < 3 * nc;
+            L.Jc()[e] = act ? L.Jall[(3 * feet[act ? a / 3 : 0] + a % 3) * 18 + j] : 0.0;
+        }
+        if (tid < 12) {
+            const bool act = tid < 3 * nc;
+            const int f = act ? feet[tid / 3] : 0, r = tid % 3;
+            L.gam[tid] = (act && mode == 0) ? (L.Jdv[3 * f + r] + 2.0 * alpha * L.fvel[3 * f + r]) : 0.0;
+            L.grf[tid] = 0.0;
+        })
 }
-// G = X^T X (12x12, padded rows/cols get the identity) and rhs; X = Xm (18x12)
-HD void wb_gram(WbCore& L, int m, int tid, double rhs_dot) {
-    _Pragma("unroll")
-    for (int a = 0; a < 12; a++) {
+// G = X^T X (12x12, padded rows/cols get the identity), 144 entries dealt over the wave ; X = Xm (18x12)
+HD void wb_gram(WbCore& L, int m, int tid, int nt) {
+    for (int e = tid; e < 144; e += nt) {
+        const int a = e / 12, b = e % 12;
         double s = 0;
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.Xm()[i * 12 + tid];
-        L.G()[a * 12 + tid] = (tid >= m || a >= m) ? ((a == tid) ? 1.0 : 0.0) : s;
-        HS_CBAR();
+        for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.Xm()[i * 12 + b];
+        L.G()[e] = (b >= m || a >= m) ? ((a == b) ? 1.0 : 0.0) : s;
     }
-    L.rhs[tid] = (tid < m) ? (-rhs_dot - L.gam[tid]) : 0.0;
 }
 
 // Contact solve WITHOUT forming M^-1 (rollout): M = L L^T in place, X = L^-1 Jc^T, G = X^T X (+damping),
@@ -195,7 +207,9 @@ template <int NT>
 HD void wb_kkt_direct(WbCore& L, int nc, const int* feet, int mode, double alpha) {
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
-    chol_s<NT, 18, 18>(L.M, L.M, L.rdM, 0.0);
+    LQ_STAMP(7)
+    chol_f<NT, 18, 18>(L.M, L.M, L.rdM, 0.0);
+    LQ_STAMP(8)
     HS_PHASE(NT, if (tid < 12) {             // X[:, tid] = L^-1 Jc[tid, :]^T
         double x[18];
         _Pragma("unroll")
@@ -211,13 +225,17 @@ HD void wb_kkt_direct(WbCore& L, int nc, const int* feet, int mode, double alpha
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) L.a0[i] = y[i];
     })
-    HS_PHASE(NT, if (tid < 12) {
-        double s = 0;
-        if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + tid] * L.a0[i]; }
-        else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[tid * 18 + i] * L.x[18 + i]; }
-        wb_gram(L, m, tid, s);
-    })
-    chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    HS_PHASE(NT, wb_gram(L, m, tid, NT);
+        if (tid >= 48 && tid < 60) {
+            const int a = tid - 48; double s = 0;
+            if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.a0[i]; }
+            else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.x[18 + i]; }
+            L.rhs[a] = (a < m) ? (-s - L.gam[a]) : 0.0;
+        })
+    LQ_STAMP(9)
+    chol_f<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    LQ_STAMP(10)
+#ifdef HS_HOST_EMU
     HS_PHASE(NT, if (tid == 0) {             // lam = G^-1 rhs ; then z = y + X lam ; back substitution L^T qdd = z
         double lam[12];
         _Pragma("unroll")
@@ -232,73 +250,55 @@ HD void wb_kkt_direct(WbCore& L, int nc, const int* feet, int mode, double alpha
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
     })
+#else
+    // lam = G^-1 rhs ; z = y + X lam ; back substitution L^T qdd = z — across the lanes of the wave: lane i owns entry i, the
+    // entry just finished travels by lane broadcast, the factor entries each lane needs are preloaded from LDS
+    HS_PHASE(NT, {
+        const int i12 = tid < 12 ? tid : 11, i18 = tid < 18 ? tid : 17;
+        double lgr[12], lgc[12], xr[12], lmc[18];
+        _Pragma("unroll") for (int k = 0; k < 12; k++) { lgr[k] = L.LG()[i12 * 12 + k]; lgc[k] = L.LG()[k * 12 + i12]; xr[k] = L.Xm()[i18 * 12 + k]; }
+        _Pragma("unroll") for (int k = 0; k < 18; k++) lmc[k] = L.M[k * 18 + i18];
+        const double rg = L.rdG[i12], rm = L.rdM[i18];
+        double v = L.rhs[i12];
+        _Pragma("unroll") for (int k = 0; k < 12; k++) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid > k) ? v - lgr[k] * xk : v); }
+        _Pragma("unroll") for (int k = 11; k >= 0; k--) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid < k) ? v - lgc[k] * xk : v); }
+        double z = L.a0[i18];
+        _Pragma("unroll") for (int a = 0; a < 12; a++) z += xr[a] * hs_readlane(v, a);
+        _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
+        if (tid < 18) L.qdd[tid] = z + ((mode == 1) ? L.x[18 + tid] : 0.0);
+        if (tid < 12) { L.lam[tid] = v; if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = v; }
+    })
+#endif
 }
 
-// Contact solve WITH M^-1 and the KKT-matrix inverse (LQ).  Kinv: 30x30 (ld 30), padded rows/cols are zero
-// (Pinocchio computeKKTContactDynamicMatrixInverse / getKKTContactDynamicMatrixInverse, damping 0).
-template <int NT>
-HD void wb_kkt_full(WbCore& L, WbDeriv& D, int nc, const int* feet, int mode, double alpha) {
-    const int m = 3 * nc;
-    wb_select<NT>(L, nc, feet, mode, alpha);
-    chol_s<NT, 18, 18>(L.M, D.Lm(), L.rdM, 0.0);
-    LQ_STAMP(7)
-    HS_PHASE(NT, if (tid < 18) inv_col_s<18, 18>(D.Lm(), L.rdM, D.Minv, 18, tid);)
-    LQ_STAMP(8)
-    HS_PHASE(NT, if (tid < 18) {
-        double s = 0;
-        if (mode == 0) { _Pragma("unroll") for (int j = 0; j < 18; j++) s += D.Minv[tid * 18 + j] * (L.tau[j] - L.h[j]); } else s = L.x[18 + tid];
-        L.a0[tid] = s;
-    } else if (tid >= 32 && tid < 44) {      // X[:, a] = Minv Jc[a, :]^T
-        const int a = tid - 32;
+// One column of the KKT-inverse products the LQ approximation needs, WITHOUT forming M^-1 or the KKT inverse (the
+// reference asks Pinocchio for the 30x30 inverse, WBM.cpp:463,512, and multiplies): with M = L L^T, X = L^-1 Jc^T, G = X^T X
+//   [M Jc^T; Jc 0]^-1 [top; bot] = [ L^-T (y - X nu) ; nu ],   y = L^-1 top,  nu = G^-1 (X^T y - bot)
+// every lane solves its own right-hand side in registers; factors are read from LDS as broadcasts.
+// in: top[18] (or y directly if top_is_y), bot[12] (entries >= m zero) ; out: top <- upper part, bot <- nu
+HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bot, bool top_is_y) {
+    if (!top_is_y) fwd_s<18, 18>(L.M, L.rdM, top);
+    _Pragma("unroll")
+    for (int a = 0; a < 12; a++) {
+        double s = -bot[a];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) { double s = 0; _Pragma("unroll") for (int j = 0; j < 18; j++) s += D.Minv[i * 18 + j] * L.Jc()[a * 18 + j]; L.Xm()[i * 12 + a] = s; }
-    })
-    HS_PHASE(NT, if (tid < 12) {
+        for (int i = 0; i < 18; i++) s += L.JX[216 + i * 12 + a] * top[i];
+        bot[a] = s;
+    }
+    fwd_s<12, 12>(D.LGs, D.rdGs, bot); bwd_s<12, 12>(D.LGs, D.rdGs, bot);
+    _Pragma("unroll")
+    for (int i = 0; i < 18; i++) {
+        double s = top[i];
         _Pragma("unroll")
-        for (int a = 0; a < 12; a++) {       // G = Jc Minv Jc^T
-            double s = 0;
-            _Pragma("unroll")
-            for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.Xm()[i * 12 + tid];
-            L.G()[a * 12 + tid] = (tid >= m || a >= m) ? ((a == tid) ? 1.0 : 0.0) : s;
-        }
-        double s = 0;
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) s += L.Jc()[tid * 18 + i] * L.a0[i];
-        L.rhs[tid] = (tid < m) ? (-s - L.gam[tid]) : 0.0;
-    })
-    LQ_STAMP(9)
-    chol_s<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
-    LQ_STAMP(10)
-    HS_PHASE(NT, if (tid == 0) {
-        double lam[12];
-        _Pragma("unroll")
-        for (int i = 0; i < 12; i++) lam[i] = L.rhs[i];
-        fwd_s<12, 12>(L.LG(), L.rdG, lam); bwd_s<12, 12>(L.LG(), L.rdG, lam);
-        _Pragma("unroll")
-        for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
-    })
-    HS_PHASE(NT, if (tid < 18) { double s = L.a0[tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[tid * 12 + a] * L.lam[a]; L.qdd[tid] = s; })
-    LQ_STAMP(11)
-    // the KKT inverse reuses the factor of the forward solve: Pinocchio's computeKKTContactDynamicMatrixInverse uses damping 0,
-    // forwardDynamics 1e-12; keeping one factor changes Lambda by <= 1e-12 * cond(J Minv J^T) relative (1e-11 here).
-    HS_PHASE(NT, if (tid < 12) inv_col_s<12, 12>(L.LG(), L.rdG, D.Lam(), 12, tid);)
-    LQ_STAMP(12)
-    HS_PHASE(NT, if (tid < 12) {             // Y = X Lam with padded rows/cols of Lam forced to zero
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) { double s = 0; _Pragma("unroll") for (int b = 0; b < 12; b++) s += L.Xm()[i * 12 + b] * D.Lam()[b * 12 + tid]; D.Ym()[i * 12 + tid] = (tid < m) ? s : 0.0; }
-    })
-    HS_PHASE(NT, if (tid < 18) {
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) { double s = D.Minv[i * 18 + tid]; _Pragma("unroll") for (int a = 0; a < 12; a++) s -= D.Ym()[i * 12 + a] * L.Xm()[tid * 12 + a]; D.Kinv[i * 30 + tid] = s; }
-        _Pragma("unroll")
-        for (int a = 0; a < 12; a++) { D.Kinv[(18 + a) * 30 + tid] = D.Ym()[tid * 12 + a]; D.Kinv[tid * 30 + 18 + a] = D.Ym()[tid * 12 + a]; }
-    } else if (tid >= 32 && tid < 44) {
-        const int a = tid - 32;
-        _Pragma("unroll")
-        for (int b = 0; b < 12; b++) D.Kinv[(18 + b) * 30 + 18 + a] = (a < m && b < m) ? -D.Lam()[b * 12 + a] : 0.0;
-    })
+        for (int a = 0; a < 12; a++) s -= L.JX[216 + i * 12 + a] * bot[a];
+        top[i] = s;
+    }
+    bwd_s<18, 18>(L.M, L.rdM, top);
 }
-
+// keep the Schur factor of wb_kkt_direct: GG is about to receive the foot tangents
+template <int NT> HD void wb_keep_schur(WbCore& L, WbDeriv& D) {
+    HS_PHASE(NT, for (int i = tid; i < 144; i += NT) D.LGs[i] = L.LG()[i]; if (tid < 12) D.rdGs[tid] = L.rdG[tid];)
+}
 
 // Tangent pass: lanes 0..35: d ID(q,v,acc)/dx_lane (psi_dyn, gravity `grav`); lanes 36..53: massless, foot forces L.fext,
 // psi_kin, tangent on q_(lane-36): tau tangent = -d(J^T F)/dq, foot acc / vel tangents.
@@ -541,43 +541,43 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     LQ_STAMP0()
     wb_terms<NT>(L, md, true);
     LQ_STAMP(0)
-    wb_kkt_full<NT>(L, D, P.nc, P.feet, 0, P.bg_alpha);
+    wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
+    wb_keep_schur<NT>(L, D);
     LQ_STAMP(1)
     const int m = 3 * P.nc;
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid]; if (tid < 12) L.fext[tid] = L.grf[tid];)
     wb_dpass<NT>(L, D, md, GRAV, 1.0, 1.0, 1.0, false);
     LQ_STAMP(2)
-    // column d of the continuous partials: top = d tau - d(J^T F) (18), bot = d(foot acc) + Baumgarte terms (m)
-    HS_PHASE(NT, if (tid < 36) {
+    // lane d < 36: column d of the continuous partials, right-hand side top = d tau - d(J^T F) (18), bot = d(foot acc) + Baumgarte
+    // terms (m) -> column d of A (rows 18..35) and of C ; lanes 36..47: unit torque j -> column j of B and of D
+    HS_PHASE(NT, if (tid < 48) {
         const int d = tid;
         double top[18], bot[12];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0);   // lanes 36+: tau tangent = -dJTF
+        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0)) : ((i == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) {
             bot[a] = 0.0;
-            if (a < m) {
+            if (a < m && d < 36) {
                 const int r = 3 * P.feet[a / 3] + a % 3;
                 if (d < 18) bot[a] = L.G()[r * 18 + d] + 2.0 * P.bg_alpha * L.dvel()[r * 18 + d];
                 else bot[a] = 2.0 * L.dvel()[r * 18 + (d - 18)] + 2.0 * P.bg_alpha * L.Jall[r * 18 + (d - 18)];   // footAccPartialDv == 2 footVelPartialDq
             }
         }
-        for (int i = 0; i < 18; i++) {     // rows 18..35 of A, kept in W rows 18..35
-            double s = 0;
-        _Pragma("unroll")
-            for (int j = 0; j < 18; j++) s -= D.Kinv[i * 30 + j] * top[j];
-        _Pragma("unroll")
-            for (int a = 0; a < 12; a++) s -= D.Kinv[i * 30 + 18 + a] * bot[a];     // padded columns of Kinv are zero
-            D.W[WR0 + i * 36 + d] = s * dt + ((d == 18 + i) ? 1.0 : 0.0);
-        }
-        for (int a = 0; a < 12; a++) L.Jc()[a + 12 * d] = 0.0;
-        for (int a = 0; a < m; a++) {
-            double s = 0;
-        _Pragma("unroll")
-            for (int j = 0; j < 18; j++) s += D.Kinv[(18 + a) * 30 + j] * top[j];
-        _Pragma("unroll")
-            for (int b2 = 0; b2 < 12; b2++) s += D.Kinv[(18 + a) * 30 + 18 + b2] * bot[b2];
-            L.Jc()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = s;
+        wb_kkt_column(L, D, top, bot, false);
+        if (d < 36) {
+            _Pragma("unroll")
+            for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = -top[i] * dt + ((d == 18 + i) ? 1.0 : 0.0);     // rows 18..35 of A
+            _Pragma("unroll")
+            for (int a = 0; a < 12; a++) D.stC()[a + 12 * d] = 0.0;
+            for (int a = 0; a < m; a++) D.stC()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = bot[a];
+        } else {
+            const int j = d - 36;
+            _Pragma("unroll")
+            for (int i = 0; i < 18; i++) D.stB()[i + 18 * j] = top[i] * dt;
+            _Pragma("unroll")
+            for (int a = 0; a < 12; a++) D.stD()[a + 12 * j] = 0.0;
+            for (int a = 0; a < m; a++) D.stD()[(3 * P.feet[a / 3] + a % 3) + 12 * j] = -bot[a];
         }
     })
     LQ_STAMP(3)
@@ -586,11 +586,10 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         const int r = e % 36, c = e / 36;
         P.A[kk * P.rs + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
     })
-    store_block<NT>(P.C + kk * P.rs, L.Jc(), 432);
+    store_block<NT>(P.C + kk * P.rs, D.stC(), 432);
     HS_PHASE_L(NT,
-        for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.Kinv[(r - 18) * 30 + 6 + j] * dt; }
-        for (int e = tid; e < 144; e += NT) { const int r = e % 12, j = e / 12, f = r / 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = 3 * t + r % 3;
-            P.D[kk * P.rs + e] = (a >= 0) ? -D.Kinv[(18 + a) * 30 + 6 + j] : 0.0; })
+        for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; }
+        for (int e = tid; e < 144; e += NT) P.D[kk * P.rs + e] = D.stD()[e];)
     LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
@@ -685,7 +684,8 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     // ---- impact partial (WBM.cpp:508-543)
     int tdfeet[4]; int ntd = 0; for (int f = 0; f < 4; f++) if (P.td[f]) tdfeet[ntd++] = f;
     const int m = 3 * ntd;
-    wb_kkt_full<NT>(L, D, ntd, tdfeet, 1, 0.0);    // L.qdd = v+, L.lam = impulse_c (compact), Kinv
+    wb_kkt_direct<NT>(L, ntd, tdfeet, 1, 0.0);    // L.qdd = v+, L.lam = impulse_c (compact); factors L (in M), X, Schur factor
+    wb_keep_schur<NT>(L, D);
     // pass A: d(M dv)/dq (v = 0, acc = v+ - v, gravity off) on lanes 0..17; d(J^T imp)/dq with the mis-sliced impulse (quirk v)
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid] - L.x[18 + tid]; if (tid < 12) L.fext[tid] = 0.0;)
     HS_PHASE(NT, if (tid == 0) { double pad[16]; for (int i = 0; i < 16; i++) pad[i] = i < m ? L.lam[i] : 0.0;
@@ -701,18 +701,22 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
             C->dvel()[(3 * f) * 18 + j] = v.x.d; C->dvel()[(3 * f + 1) * 18 + j] = v.y.d; C->dvel()[(3 * f + 2) * 18 + j] = v.z.d; } } sk{&L, tid - 36};
         wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
     })
-    // Px = [I 0; dv+/dq dv+/dv] , dv+/dq = -TL*dtau_dq - TR*dv_dq ; dv+/dv = TL*M ; staged in W rows (column d per lane)
+    // Px = [I 0; dv+/dq dv+/dv] , dv+/dq = -(K^-1 [dtau_dq; dv_dq])_top ; dv+/dv = (K^-1 [M; 0])_top, where the column M e_j = L L^T e_j
+    // enters the solve directly as y = L^T e_j ; staged in W rows (column d per lane)
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
+        double top[18], bot[12];
+        _Pragma("unroll")
         for (int i = 0; i < 18; i++) {
-            double s = 0;
-            if (d < 18) {
-                for (int j = 0; j < 18; j++) s -= D.Kinv[i * 30 + j] * D.W[j * WT + d];
-                for (int a = 0; a < m; a++) s -= D.Kinv[i * 30 + 18 + a] * L.dvel()[(3 * tdfeet[a / 3] + a % 3) * 18 + d];
-            } else { for (int j = 0; j < 18; j++) s += D.Kinv[i * 30 + j] * L.M[j * 18 + (d - 18)]; }
-            // results into rows 18..35 of W (rows 0..17 still hold the tangents other lanes read)
-            D.W[WR0 + i * 36 + d] = s;
+            if (d < 18) top[i] = D.W[i * WT + d];
+            else { const int j = d - 18; top[i] = (i < j) ? L.M[j * 18 + i] : (i == j) ? 1.0 / L.rdM[j] : 0.0; }
         }
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) bot[a] = (d < 18 && a < m) ? L.dvel()[(3 * tdfeet[a / 3] + a % 3) * 18 + d] : 0.0;
+        wb_kkt_column(L, D, top, bot, d >= 18);
+        // results into rows 18..35 of W (rows 0..17 still hold the tangents other lanes read)
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = (d < 18) ? -top[i] : top[i];
     })
     HS_PHASE(NT, for (int e = tid; e < nn * 36; e += NT) {
         const int r = e % nn, c = e / nn;
