@@ -203,40 +203,91 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
     else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
 
+// Several 16x16 output tiles of ONE wave, accumulated together: the k-loop is outermost so that the MFMAs issued back to
+// back belong to different accumulators (a tile's own MFMAs form a dependent chain) and all operand loads of a k-step are in
+// flight together.  A tile may chain a second product onto the same accumulator (A^T HA + C^T lC).
+struct MTile {
+    double* Cout; int ldc; const double* Cin; int ldcin; int i0, j0, M_, N_;
+    const double* A; int lda; const double* B; int ldb; int K; bool TA;
+    const double* A2; int lda2; const double* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
+};
+template <int NTL, int KMAX, int KMAX2>
+HD void mfma_tiles(int lane, const MTile* td) {
+#ifdef HS_HOST_EMU
+    if (lane != 0) return;     // the emulator lets lane 0 stand for the wave (plain loops); the lane mapping is verified on the GPU
+    for (int t = 0; t < NTL; t++) {
+        const MTile& T = td[t];
+        for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
+            double s = T.Cin ? T.Cin[i + T.ldcin * j] : 0.0;
+            for (int k = 0; k < T.K; k++) s += (T.TA ? T.A[k + T.lda * i] : T.A[i + T.lda * k]) * T.B[k + T.ldb * j];
+            for (int k = 0; k < T.K2; k++) s += T.A2[k + T.lda2 * i] * T.B2[k + T.ldb2 * j];
+            T.Cout[i + T.ldc * j] = s;
+        }
+    }
+#else
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t c[NTL];
+    _Pragma("unroll") for (int t = 0; t < NTL; t++) {
+        const int j = td[t].j0 + li;
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? td[t].Cin[row + td[t].ldcin * j] : 0.0; }
+    }
+    _Pragma("unroll") for (int kg = 0; kg < KMAX / 4; kg++) {
+        _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K) {
+            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
+            const double a = (i < td[t].M_) ? (td[t].TA ? td[t].A[k + td[t].lda * i] : td[t].A[i + td[t].lda * k]) : 0.0;
+            const double b = (j < td[t].N_) ? td[t].B[k + td[t].ldb * j] : 0.0;
+            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
+        }
+    }
+    _Pragma("unroll") for (int kg = 0; kg < KMAX2 / 4; kg++) {
+        _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K2) {
+            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
+            const double a = (i < td[t].M_) ? td[t].A2[k + td[t].lda2 * i] : 0.0;
+            const double b = (j < td[t].N_) ? td[t].B2[k + td[t].ldb2 * j] : 0.0;
+            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
+        }
+    }
+    _Pragma("unroll") for (int t = 0; t < NTL; t++) {
+        const int j = td[t].j0 + li;
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; if (row < td[t].M_ && j < td[t].N_) td[t].Cout[row + td[t].ldc * j] = c[t][r]; }
+    }
+#endif
+}
+
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
 template <int W, int N, int M, int PY>
 HD void sweep_tiles1(SweepLdsT<N, M, PY>& S, int lane) {
     constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
-    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;
+    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16, TPd = TP > 0 ? TP : 1;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
-    _Pragma("unroll") for (int t = W; t < t4; t += 4) {
-        if (t < t1) mfma_tile<false, N>(lane, S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN);
-        else if (t < t2) mfma_tile<false, N>(lane, S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN);
-        else if (t < t3) mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lC, LDM, nullptr, 0, 16 * ((t - t2) % (TP > 0 ? TP : 1)), 16 * ((t - t2) / (TP > 0 ? TP : 1)), PY, N, S.lyy, LDM, S.C, LDM);
-        else mfma_tile<false, (PY > 0 ? PY : 4)>(lane, S.lD, LDM, nullptr, 0, 16 * ((t - t3) % (TP > 0 ? TP : 1)), 16 * ((t - t3) / (TP > 0 ? TP : 1)), PY, M, S.lyy, LDM, S.D, LDM);
+    constexpr int NTL = (t4 - W + 3) / 4;
+    if (NTL <= 0) return;
+    MTile td[NTL > 0 ? NTL : 1];
+    _Pragma("unroll") for (int q = 0; q < NTL; q++) {
+        const int t = W + 4 * q;
+        if (t < t1) td[q] = MTile{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN, N, false, nullptr, 0, nullptr, 0, 0};
+        else if (t < t2) td[q] = MTile{S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN, N, false, nullptr, 0, nullptr, 0, 0};
+        else if (t < t3) td[q] = MTile{S.lC, LDM, nullptr, 0, 16 * ((t - t2) % TPd), 16 * ((t - t2) / TPd), PY, N, S.lyy, LDM, S.C, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
+        else td[q] = MTile{S.lD, LDM, nullptr, 0, 16 * ((t - t3) % TPd), 16 * ((t - t3) / TPd), PY, M, S.lyy, LDM, S.D, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
     }
+    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, 0>(lane, td);
 }
 template <int W, int N, int M, int PY>
 HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
     constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
-    _Pragma("unroll") for (int t = W; t < t3; t += 4) {
-        if (t < t1) {
-            const int i0 = 16 * (t % TN), j0 = 16 * (t / TN);
-            mfma_tile<true, N>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.A, LDN, S.HA, LDN);
-            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qxx, LDN, S.Qxx, LDN, i0, j0, N, N, S.C, LDM, S.lC, LDM);
-        } else if (t < t2) {
-            const int i0 = 16 * ((t - t1) % TM), j0 = 16 * ((t - t1) / TM);
-            mfma_tile<true, N>(lane, S.Qux, LDM, nullptr, 0, i0, j0, M, N, S.B, LDN, S.HA, LDN);
-            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Qux, LDM, S.Qux, LDM, i0, j0, M, N, S.D, LDM, S.lC, LDM);
-        } else {
-            const int i0 = 16 * ((t - t2) % TM), j0 = 16 * ((t - t2) / TM);
-            mfma_tile<true, N>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.B, LDN, S.HB, LDN);
-            if (PY > 0) mfma_tile<true, (PY > 0 ? PY : 4)>(lane, S.Quu, LDM, S.Quu, LDM, i0, j0, M, M, S.D, LDM, S.lD, LDM);
-        }
+    constexpr int NTL = (t3 - W + 3) / 4;
+    if (NTL <= 0) return;
+    MTile td[NTL > 0 ? NTL : 1];
+    _Pragma("unroll") for (int q = 0; q < NTL; q++) {
+        const int t = W + 4 * q;
+        if (t < t1) td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY};
+        else if (t < t2) td[q] = MTile{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
+        else td[q] = MTile{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY};
     }
+    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4>(lane, td);
 }
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
