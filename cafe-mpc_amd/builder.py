@@ -1,0 +1,236 @@
+"""Host-side problem builder: the counterpart of MHPCProblem<T>::initialization (MHPC/MHPC-Trajopt/MHPCProblem.cpp:14-249,
+403-601) and of the gait-reference loader QuadReference (Reference/QuadReference.cpp:5-408), emitting the POD phase
+descriptors of include/hsddp.h instead of SinglePhase objects with closures.
+
+Everything the reference does in `float` is done in numpy float32 here (time accumulation, nearest-sample lookup,
+std::stof parsing: SURVEY quirk vii), so that phase boundaries and reference indices come out identically.
+"""
+import json
+import os
+import re
+
+import numpy as np
+
+from ._abi import MODEL_WB, MODEL_SRB, Reb, Al, mhpc_ddp_setting
+from . import problems
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------------- settings files
+def load_info(path):
+    """boost::property_tree INFO file -> {section: {key: string}} (loadMHPCConfig MHPCProblem.h:66-84, load_reb_params ...)."""
+    out, cur = {}, None
+    for raw in open(path):
+        line = raw.split(";")[0].strip()
+        if not line:
+            continue
+        if line == "{" or line == "}":
+            if line == "}":
+                cur = None
+            continue
+        toks = line.split()
+        if len(toks) == 1:
+            cur = toks[0]; out[cur] = {}
+        elif cur is not None:
+            out[cur][toks[0]] = toks[1]
+    return out
+
+
+def load_mhpc_config(path):
+    c = load_info(path)["config"]
+    return dict(plan_dur_wb=float(c["plan_dur_wb"]), plan_dur_srb=float(c["plan_dur_srb"]), dt_mpc=F32(float(c["dt_mpc"])),
+                dt_wb=float(c["dt_wb"]), dt_srb=float(c["dt_srb"]), BG_alpha=float(F32(float(c["BG_alpha"]))),
+                referenceFile=c["referenceFile"], costFile=c["costFile"], constraintParamFile=c["constraintParamFile"])
+
+
+def load_constraint_params(path):
+    p = load_info(path)
+    reb = lambda n: Reb(float(p[n + "_ReB"]["delta"]), float(p[n + "_ReB"]["delta_min"]), float(p[n + "_ReB"]["eps"]))
+    td = p["TD_AL"]
+    return dict(grf=reb("GRF"), torque=reb("Torque"), jointspeed=reb("JointSpeed") if "JointSpeed_ReB" in p else reb("Joint"), joint=reb("Joint"),
+                minheight=reb("MinHeight"), td=Al(float(td["sigma"]), float(td["lambda"]), float(td["sigma_max"])))
+
+
+def load_cost_weights(path):
+    """loadCostWeights (MHPCCostUtil.h:21-140): [q(36), r(12), qf(36)] for WB, [q(12), r(12), qf(12)] for SRB, 3-vectors per foot cost."""
+    j = json.load(open(path))
+    w = j["WB_Tracking_Cost"]; s = j["SRB_Tracking_Cost"]
+    return dict(
+        wb_q=list(w["qw_qB"]) + list(w["qw_qJ"]) * 4 + list(w["qw_vB"]) + list(w["qw_vJ"]) * 4, wb_r=[w["rw"]] * 12,
+        wb_qf=list(w["qfw_qB"]) + list(w["qfw_qJ"]) * 4 + list(w["qfw_vB"]) + list(w["qfw_vJ"]) * 4,
+        srb_q=list(s["qw_qB"]) + list(s["qw_vB"]), srb_r=[s["rw"]] * 12, srb_qf=list(s["qfw_qB"]) + list(s["qfw_vB"]),
+        foot_reg=list(j["WB_FootPlace_Reg"]["qw_per_foot"]), swing_pos=list(j["Swing_Pos_Tracking"]["qw_per_foot"]),
+        swing_vel=list(j["Swing_Vel_Tracking"]["qw_per_foot"]))
+
+
+# --------------------------------------------------------------------------------------------- gait reference
+class QuadReference:
+    """QuadReference (Reference/QuadReference.h, .cpp): top-level gait data + nearest-sample lookups in float arithmetic."""
+    FIELDS = {"body_state": 12, "jnt_angle": 12, "jnt_vel": 12, "foot_placements": 12, "foot_velocities": 12, "grf": 12, "torque": 12,
+              "contact": 4, "status_dur": 4}
+
+    def __init__(self, path, reorder=False):
+        cols = {k: [] for k in self.FIELDS}
+        cur = {k: np.zeros(w) for k, w in self.FIELDS.items()}
+        lines = open(path).read().split("\n")
+        i = 0
+        self.dt = F32(0)
+        while i < len(lines):
+            line = lines[i]; i += 1
+            if line == "dt":
+                self.dt = F32(lines[i]); i += 1; continue
+            key = next((k for k in ("body_state", "jnt_angle", "jnt_vel", "foot_placements", "foot_velocities", "foot_height", "grf", "torque",
+                                    "contact", "status_dur") if k in line), None)     # same test order as load_top_level_data (:160-332)
+            if key is None:
+                continue
+            words = lines[i].split(); i += 1
+            if key == "foot_height":
+                continue
+            if key == "body_state":
+                cur = {k: np.zeros(w) for k, w in self.FIELDS.items()}       # quad_state.SetZero()
+            w = self.FIELDS[key]
+            vals = [int(x) for x in words[:w]] if key == "contact" else [float(F32(x)) for x in words[:w]]      # std::stoi / std::stof
+            cur[key][:len(vals)] = vals
+            if key == "status_dur":
+                for k in cols:
+                    cols[k].append(cur[k].copy())
+        self.tp = {k: np.array(v) for k, v in cols.items()}
+        b = self.tp["body_state"]                                             # reorder_body_states: [eul,pos,omega,v] -> [pos,eul,v,omega]
+        self.tp["body_state"] = np.concatenate([b[:, 3:6], b[:, 0:3], b[:, 9:12], b[:, 6:9]], axis=1)
+        if reorder:                                                            # reorder_leg_dependent_states (:362-407)
+            sw = lambda a: np.concatenate([a[:, 3:6], a[:, 0:3], a[:, 9:12], a[:, 6:9]], axis=1)
+            for k in ("jnt_angle", "foot_placements", "foot_velocities", "grf", "torque"):
+                self.tp[k] = sw(self.tp[k])
+            self.tp["jnt_vel"] = np.zeros_like(self.tp["jnt_vel"])
+            self.tp["contact"] = self.tp["contact"][:, [1, 0, 3, 2]]; self.tp["status_dur"] = self.tp["status_dur"][:, [1, 0, 3, 2]]
+        self.k_cur = 0; self.sz = 0
+
+    def __len__(self):
+        return self.tp["contact"].shape[0]
+
+    def initialize(self, plan_horizon):                                        # QuadReference::initialize (:5-21)
+        self.k_cur = 0
+        self.sz = int(round(float(F32(plan_horizon)) / float(self.dt))) + 1
+        assert self.sz + 1 <= len(self), "reference file shorter than the planning horizon"
+
+    def step(self, dt_sim):                                                    # QuadReference::step (:28-45)
+        i = 1
+        while float(F32(i) * self.dt) < float(F32(dt_sim)) or abs(float(F32(i) * self.dt) - float(F32(dt_sim))) <= 1e-6:
+            self.k_cur += 1; i += 1
+
+    def index(self, t):                                                        # get_a_reference_ptr_at_t (:63-76)
+        t = F32(t)
+        k = int(np.floor(t / self.dt))
+        if float(F32(t - F32(k) * self.dt)) > 0.5 * float(self.dt):
+            k += 1
+        return min(k, self.sz - 1)
+
+    def at(self, t):
+        k = self.k_cur + self.index(t)
+        return {n: self.tp[n][k] for n in self.tp}
+
+    def contact_at(self, t):
+        return self.tp["contact"][self.k_cur + self.index(t)].astype(np.int32)
+
+
+def _approx_eq(a, b):      # HSDDP_Utils.h:46-56 (float tolerance, float error)
+    return float(F32(abs(float(a) - float(b)))) <= float(F32(1e-6))
+
+
+def _approx_leq(a, b):
+    return float(a) < float(b) or _approx_eq(a, b)
+
+
+# --------------------------------------------------------------------------------------------- MHPC problem
+def build_mhpc_problem(ref, config, costs, cpar, ubar_mode="zero"):
+    """MHPCProblem::prepare_initialization + initialize_multiPhaseProblem at the current reference time.
+    Returns (phases, info) where info holds the phase table of MHPCProblemData (start/end times, horizons, contacts, durations)."""
+    dt_wb, dt_srb = config["dt_wb"], config["dt_srb"]
+    plan_all = F32(config["plan_dur_wb"] + config["plan_dur_srb"])
+    ref.initialize(plan_all)
+    starts, ends, hors, contacts, durs = [], [], [], [], []
+    if config["plan_dur_wb"] > 1e-5:                                          # MHPCProblem.cpp:69-108
+        t = F32(0); start = F32(0)
+        c_prev = ref.contact_at(t); d_prev = ref.at(t)["status_dur"].copy()
+        while _approx_leq(t, config["plan_dur_wb"]):
+            c_cur = ref.contact_at(t)
+            if (c_cur != c_prev).any() or _approx_eq(t, config["plan_dur_wb"]):
+                end = t
+                starts.append(start); ends.append(end); hors.append(int(round(float(F32(end - start)) / dt_wb)))
+                contacts.append(c_prev.copy()); durs.append(d_prev.copy())
+                c_prev = c_cur; d_prev = ref.at(t)["status_dur"].copy(); start = end
+            t = F32(float(t) + dt_wb)
+    n_wb = len(starts)
+    srb_h = int(round(config["plan_dur_srb"] / dt_srb)) if config["plan_dur_srb"] > 1e-5 else 0
+    srb_start = F32(config["plan_dur_wb"])
+    phases = []
+    for i in range(n_wb):
+        h = hors[i]
+        nxt = contacts[i + 1] if i + 1 < n_wb else ref.contact_at(F32(config["plan_dur_wb"] + float(config["dt_mpc"])))   # :532-540
+        t_off = float(F32(starts[i] - starts[0]))
+        xr = np.zeros((h + 1, 36)); ur = np.zeros((h + 1, 12)); yr = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); fv = np.zeros((h + 1, 12))
+        bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32); X0 = np.zeros((h + 1, 36))
+        for k in range(h + 1):
+            a = ref.at(F32(t_off + k * dt_wb))                                 # cost / constraint lookups at t_offset + k dt (SinglePhase.cpp:243,298)
+            b = a["body_state"]
+            xr[k] = np.concatenate([b[:6], a["jnt_angle"], b[6:], a["jnt_vel"]])      # WBReference::get_reference_at_t (MHPCReference.cpp:24-39)
+            ur[k] = a["torque"]; yr[k] = a["grf"]; fp[k] = a["foot_placements"]; fv[k] = a["foot_velocities"]; bp[k] = b[:3]; rc[k] = a["contact"]
+            a0 = ref.at(F32(float(starts[i]) + k * dt_wb))                     # initial guess lookup (MHPCProblem.cpp:186-193)
+            b0 = a0["body_state"]
+            X0[k] = np.concatenate([b0[:6], a0["jnt_angle"], b0[6:], a0["jnt_vel"]])
+        refs = dict(xr=xr, ur=ur, yr=yr, foot_pos=fp, foot_vel=fv, body_pos=bp, ref_contact=rc)
+        last = i == n_wb - 1
+        ph = problems.wb_phase(h, dt_wb, t_off, contacts[i], nxt, refs, next_model=MODEL_SRB if (last and srb_h > 0) else MODEL_WB,
+                               bg_alpha=config["BG_alpha"], ubar_mode="zero")
+        d = ph["desc"]
+        problems._set(d.q, costs["wb_q"]); problems._set(d.r, costs["wb_r"]); problems._set(d.qf, costs["wb_qf"])
+        problems._set(d.w_foot_reg, costs["foot_reg"]); problems._set(d.w_swing_pos, costs["swing_pos"]); problems._set(d.w_swing_vel, costs["swing_vel"])
+        d.reb_torque, d.reb_joint, d.reb_minheight, d.reb_grf, d.al_td = cpar["torque"], cpar["joint"], cpar["minheight"], cpar["grf"], cpar["td"]
+        ph["Xbar"] = X0
+        if ubar_mode == "gravity_comp":
+            ph["Ubar"][:] = problems.wb_gravity_comp_torque(X0[0, :18], contacts[i])
+        phases.append(ph)
+    if srb_h > 0:                                                              # MHPCProblem.cpp:216-247, 488-521
+        h = srb_h; t_off = float(srb_start)
+        xr = np.zeros((h + 1, 12)); ur = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); rc = np.zeros((h + 1, 4), dtype=np.int32); bp = np.zeros((h + 1, 3))
+        X0 = np.zeros((h + 1, 12))
+        for k in range(h + 1):
+            a = ref.at(F32(t_off + k * dt_srb))
+            xr[k] = a["body_state"]; ur[k] = a["grf"]; fp[k] = a["foot_placements"]; rc[k] = a["contact"]; bp[k] = a["body_state"][:3]
+            X0[k] = ref.at(F32(float(srb_start) + k * dt_srb))["body_state"]
+        ph = problems.srb_phase(h, dt_srb, t_off, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
+        d = ph["desc"]
+        problems._set(d.q, costs["srb_q"]); problems._set(d.r, costs["srb_r"]); problems._set(d.qf, costs["srb_qf"])
+        d.reb_minheight = cpar["minheight"]
+        ph["Xbar"] = X0
+        if ubar_mode == "gravity_comp":
+            ph["Ubar"] = ur[:h].copy()
+        phases.append(ph)
+    info = dict(start_times=[float(s) for s in starts], end_times=[float(e) for e in ends], horizons=hors, contacts=[c.tolist() for c in contacts],
+                status_durations=np.array(durs, dtype=np.float32) if durs else np.zeros((0, 4), np.float32), srb_horizon=srb_h, x0=phases[0]["Xbar"][0].copy())
+    return phases, info
+
+
+def build_from_tree(root, gait=None, ubar_mode="zero"):
+    """Convenience: read MHPC/settings/{mhpc_config.info, cost/constraint files} and Reference/Data/<gait>/quad_reference.csv
+    below a CAFE-MPC checkout `root`, like MHPCLocomotion::initialize (MHPC/MHPCLocomotion.cpp:20-40)."""
+    cfg = load_mhpc_config(os.path.join(root, "MHPC", "settings", "mhpc_config.info"))
+    costs = load_cost_weights(os.path.join(root, cfg["costFile"]))
+    cpar = load_constraint_params(os.path.join(root, cfg["constraintParamFile"]))
+    ref = QuadReference(os.path.join(root, "Reference", "Data", gait or cfg["referenceFile"], "quad_reference.csv"), reorder=False)
+    phases, info = build_mhpc_problem(ref, cfg, costs, cpar, ubar_mode=ubar_mode)
+    return phases, info, cfg
+
+
+def load_ddp_setting(path):
+    """loadHSDDPSetting (HSDDP_CompoundTypes.h:62-81): update_regularization and smooth_active are NOT read (quirk xiii)."""
+    d = load_info(path)["ddp"]
+    tf = lambda s: 1 if s.strip().lower() == "true" else 0
+    return mhpc_ddp_setting(alpha=float(d["alpha"]), gamma=float(d["gamma"]), update_penalty=float(d["update_penalty"]), update_relax=float(d["update_relax"]),
+                            update_ReB=float(d["update_ReB"]), max_DDP_iter=int(d["max_DDP_iter"]), max_AL_iter=int(d["max_AL_iter"]),
+                            max_DDP_iter_runtime=int(d["max_DDP_iter_runtime"]), max_AL_iter_runtime=int(d["max_AL_iter_runtime"]),
+                            cost_thresh=float(d["cost_thresh"]), tconstr_thresh=float(d["tconstr_thresh"]), pconstr_thresh=float(d["pconstr_thresh"]),
+                            dynamics_feas_thresh=float(d["dynamics_feas_thresh"]), merit_rho=float(d["merit_rho"]), merit_scale=float(d["merit_scale"]),
+                            merit_offset=float(d["merit_offset"]), AL_active=tf(d["AL_active"]), ReB_active=tf(d["ReB_active"]), MS=tf(d["MS"]),
+                            nsteps_per_node=int(d["nsteps_per_node"]))

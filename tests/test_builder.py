@@ -1,0 +1,63 @@
+"""Host-side problem builder (cafe_mpc_amd.builder): MHPCProblem::initialization + QuadReference restated, driven by the gait
+files and settings the reference ships (trimmed copies under tests/golden/cafe_tree, made by tests/golden/make_gait_fixture.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import pkg, ROOT
+import parity_common as pc
+
+builder = importlib.import_module(pkg.__name__ + ".builder")
+TREE = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+
+
+def test_quad_reference_loader_semantics():
+    ref = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"))
+    assert len(ref) == 90 and ref.dt == np.float32(0.01)
+    # std::stof parsing: values are float32 numbers widened to double (QuadReference.cpp:170-332)
+    bs = ref.tp["body_state"]
+    assert np.array_equal(bs, bs.astype(np.float32).astype(np.float64))
+    # reorder_body_states: file order [eul, pos, omega, vWorld] -> [pos, eul, vWorld, omega]; the file's 6th number is the body height
+    assert abs(bs[0, 2] - np.float32(0.146)) < 1e-12 or bs[0, 2] > 0.1
+    ref.initialize(0.75)
+    assert ref.sz == 76
+    # nearest-sample lookup in float arithmetic (QuadReference.cpp:63-76)
+    assert ref.index(0.0) == 0 and ref.index(0.014) == 1 and ref.index(0.016) == 2 and ref.index(10.0) == 75
+    swapped = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"), reorder=True)
+    assert np.array_equal(swapped.tp["contact"], ref.tp["contact"][:, [1, 0, 3, 2]]) and not swapped.tp["jnt_vel"].any()
+
+
+def test_mhpc_problem_from_shipped_bound_gait():
+    phases, info, cfg = builder.build_from_tree(TREE)         # mhpc_config.info: bound, 0.25 s whole-body + 0.5 s SRB
+    assert cfg["referenceFile"] == "bound" and info["horizons"] == [6, 10, 9] and info["srb_horizon"] == 10
+    assert info["contacts"] == [[1, 1, 1, 1], [1, 1, 0, 0], [0, 0, 0, 0]]
+    d = [p["desc"] for p in phases]
+    assert [x.model for x in d] == [0, 0, 0, 1] and [x.next_model for x in d][:3] == [0, 0, 1]
+    assert list(d[2].next_contact) == [0, 0, 1, 1]             # hind feet land 0.27 s into the plan: touchdown constraint + impact + projection
+    assert abs(d[0].reb_torque.delta - 1.0) < 1e-15 and abs(d[0].reb_grf.eps - 0.05) < 1e-15 and d[0].al_td.sigma == 20.0
+    assert list(d[0].q)[:6] == [0, 0, 10, 1, 2, 2] and abs(d[3].r[0] - 0.01) < 1e-15 and d[3].dt == 0.05
+    assert np.allclose(phases[0]["bufs"]["yr"][0], [0, 0, 22.5] * 4)       # GRF reference of the first sample
+    if os.path.isdir("/root/reference/Reference/Data"):        # the trimmed fixture reproduces what the full tree gives
+        p2, i2, _ = builder.build_from_tree("/root/reference")
+        assert i2["horizons"] == info["horizons"]
+        for a, b in zip(phases, p2):
+            for k in a["bufs"]:
+                assert np.array_equal(a["bufs"][k], b["bufs"][k]), k
+
+
+@pytest.mark.parametrize("gait", ["bound", "trot/dynfeas"])
+def test_oracle_solves_shipped_gaits(oracle_lib, gait):
+    phases, info, cfg = builder.build_from_tree(TREE, gait=gait, ubar_mode="gravity_comp")
+    opt = builder.load_ddp_setting(os.path.join(TREE, "MHPC/settings/ddp_setting.info"))
+    s = pkg.Solver(oracle_lib, phases, batch=1)
+    for i, p in enumerate(phases):
+        s.set_nominal(i, p["Xbar"], p["Ubar"])
+    s.set_initial_condition(info["x0"][None])
+    s.hybrid_rollout(0.0, opt); s.compute_cost(opt)
+    f0 = s.measure_dynamics_feasibility()[0]
+    s.solve(opt)
+    ia = s.info_arrays()
+    assert ia["status"][0] == 0 and ia["n_iters"][0] >= 2
+    assert ia["dyn_feas"][0] < 0.2 * f0 and ia["max_tconstr"][0] < 5e-3

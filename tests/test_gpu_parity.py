@@ -102,6 +102,25 @@ def test_full_solve_parity_hkd(hip_lib, oracle_lib):
     assert (sg.info_arrays()["n_iters"] > 3).all() and (sg.info_arrays()["max_tconstr"] < 1e-3).all()
 
 
+@pytest.mark.parametrize("gait", ["bound", "trot/dynfeas"])
+def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, gait):
+    """The MHPC problem as MHPCProblem::initialization builds it from a shipped gait file + the shipped settings
+    (cafe_mpc_amd.builder over tests/golden/cafe_tree): whole-body phases from the gait's contact changes, SRB tail, ddp_setting.info."""
+    import importlib, os
+    from conftest import ROOT
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    phases, info, cfg = builder.build_from_tree(tree, gait=gait, ubar_mode="gravity_comp")
+    opt = builder.load_ddp_setting(os.path.join(tree, "MHPC/settings/ddp_setting.info"))
+    x0 = np.vstack([info["x0"], info["x0"] + 0.01 * (pkg.problems.wb_ensemble_x0(2, 3) - pkg.problems.wb_nominal_state())])
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases), rtol=1e-5)
+    assert (sg.info_arrays()["status"] == 0).all()
+    cmd = sg.export_mpc_command(problem=0, n_steps=8, mpc_time=0.0, dt=cfg["dt_wb"], status_times=info["status_durations"][:len(phases)] if False else None)
+    assert cmd["N_mpcsteps"] == 8 and np.isfinite(cmd["feedback"]).all()
+
+
 def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib):
     """BarrelRollTO.cpp as shipped: 6 hybrid phases / 125 knots (stance, right-side stance, flight, landing, flight, stance),
     zero-torque start, br_ddp_setting.info; the first AL iteration (10 DDP iterations, line searches down to small steps)."""
