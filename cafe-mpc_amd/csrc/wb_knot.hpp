@@ -135,7 +135,10 @@ HD LaneCfg lane_cfg(const ModelDev& md, bool kin, double mscale, double grav, do
 
 // sinks: where a pass stores its outputs
 struct PSink {   // value pass: lanes 0..17 -> column `lane` of M and of all foot Jacobians; lane 18 -> bias terms
-    WbCore* L; int lane;
+    WbCore* L; int lane; int task;
+    HD void base(const V3<double>& f, const V3<double>& n) const {   // per-leg task: partial base wrench (GG is free while the terms are formed)
+        double* p = L->GG + 6 * task; p[0] = f.x; p[1] = f.y; p[2] = f.z; p[3] = n.x; p[4] = n.y; p[5] = n.z;
+    }
     HD void tau(int i, double v) const { if (lane < 18) L->M[i * 18 + lane] = v; else L->h[i] = v; }
     HD void foot(int f, const V3<double>& p, const V3<double>& v, const V3<double>& a) const {
         if (lane < 18) { L->Jall[(3 * f) * 18 + lane] = a.x; L->Jall[(3 * f + 1) * 18 + lane] = a.y; L->Jall[(3 * f + 2) * 18 + lane] = a.z; }
@@ -148,6 +151,7 @@ struct PSink {   // value pass: lanes 0..17 -> column `lane` of M and of all foo
 };
 struct DSink {   // tangent pass: d tau -> W[i][lane]; kinematic lanes (>=36) also store foot acc / vel tangents
     WbDeriv* D; WbCore* C; int lane;
+    HD void base(const V3<Dual>&, const V3<Dual>&) const {}
     HD void tau(int i, const Dual& v) const { D->W[i * WT + lane] = v.d; }
     HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>& a) const {
         if (lane >= 36) {
@@ -161,15 +165,41 @@ struct DSink {   // tangent pass: d tau -> W[i][lane]; kinematic lanes (>=36) al
 // trig table of the knot state (18 lanes in parallel)
 template <int NT> HD void wb_trig(WbCore& L) { HS_PHASE(NT, if (tid < 18) { L.cs[tid] = cos(L.x[tid]); L.sn[tid] = sin(L.x[tid]); }) }
 
-// Phase: M, h, all-foot Jacobians, Jdot*v, foot pos/vel at L.x (psi_dyn).  lanes 0..17: columns, lane 18: bias terms.
+// Phase: M, h, all-foot Jacobians, Jdot*v, foot pos/vel at L.x (psi_dyn), as 40 per-leg TASKS of about a third of a pass each:
+//   lanes 0..11  : column 6+lane (a leg joint) — only its own leg moves, one task
+//   lanes 12..35 : base column (lane-12)/4, leg (lane-12)%4 ; lanes 36..39: bias terms (h, Jdot v, foot pos/vel), leg lane-36
+// A task walks the base joints forward, ONE leg down and up, and leaves the base wrench of that leg (plus the trunk's own
+// inertial force in the leg-0 task) as a partial sum; 19 lanes then add the partials in leg order and run the base joints backward.
 template <int NT>
 HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
     wb_trig<NT>(L);
-    HS_PHASE(NT, if (tid < 19 && (need_cols || tid == 18)) {
-        LaneCfg c = (tid < 18) ? lane_cfg(md, false, 1.0, 0.0, 0.0, 0.0, 0.0, tid, -1, -1)
+    HS_PHASE(NT, if (tid < 40 && (need_cols || tid >= 36)) {
+        const int col = (tid < 12) ? 6 + tid : (tid < 36) ? (tid - 12) / 4 : 18;
+        const int leg = (tid < 12) ? tid / 3 : (tid < 36) ? (tid - 12) % 4 : tid - 36;
+        LaneCfg c = (col < 18) ? lane_cfg(md, false, 1.0, 0.0, 0.0, 0.0, 0.0, col, -1, -1)
                                : lane_cfg(md, false, 1.0, GRAV, 0.0, 1.0, 0.0, -1, -1, -1);
-        PSink sk{&L, tid};
+        c.l0 = leg; c.l1 = leg + 1; c.body = (tid >= 12) && (leg == 0); c.partial = true;
+        PSink sk{&L, col, tid};
         wb_pass<double>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
+        if (tid < 12) {    // a leg-joint column is zero on the other legs' rows and feet
+            for (int f = 0; f < 4; f++) if (f != leg) {
+                for (int r = 0; r < 3; r++) { L.M[(6 + 3 * f + r) * 18 + col] = 0.0; L.Jall[(3 * f + r) * 18 + col] = 0.0; }
+            }
+        }
+    })
+    HS_PHASE(NT, if (tid < 19 && (need_cols || tid == 18)) {
+        const int t0 = (tid < 6) ? 12 + 4 * tid : (tid < 18) ? tid - 6 : 36, nt = (tid < 6 || tid == 18) ? 4 : 1;
+        V3<double> fb = {0.0, 0.0, 0.0}, nb = fb;
+        for (int t = 0; t < nt; t++) { const double* p = L.GG + 6 * (t0 + t); fb = fb + V3<double>{p[0], p[1], p[2]}; nb = nb + V3<double>{p[3], p[4], p[5]}; }
+        PSink sk{&L, tid, 0};
+        const double c3 = L.cs[3], s3 = L.sn[3], c4 = L.cs[4], s4 = L.sn[4], c5 = L.cs[5], s5 = L.sn[5];
+        sk.tau(5, nb.x);
+        V3<double> f = rot<0, double>(c5, s5, fb), n = rot<0, double>(c5, s5, nb);
+        sk.tau(4, n.y);
+        f = rot<1, double>(c4, s4, f); n = rot<1, double>(c4, s4, n);
+        sk.tau(3, n.z);
+        f = rot<2, double>(c3, s3, f);
+        sk.tau(0, f.x); sk.tau(1, f.y); sk.tau(2, f.z);
     })
 }
 
@@ -697,7 +727,7 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     HS_PHASE(NT, if (tid < 18) { L.x[18 + tid] = L.qdd[tid]; })
     HS_PHASE(NT, if (tid >= 36 && tid < 54) {
         LaneCfg c = lane_cfg(md, true, 0.0, 0.0, 0.0, 1.0, 0.0, -1, tid - 36, -1);
-        struct VSink { WbCore* C; int j; HD void tau(int, const Dual&) const {} HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>&) const {
+        struct VSink { WbCore* C; int j; HD void tau(int, const Dual&) const {} HD void base(const V3<Dual>&, const V3<Dual>&) const {} HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>&) const {
             C->dvel()[(3 * f) * 18 + j] = v.x.d; C->dvel()[(3 * f + 1) * 18 + j] = v.y.d; C->dvel()[(3 * f + 2) * 18 + j] = v.z.d; } } sk{&L, tid - 36};
         wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
     })

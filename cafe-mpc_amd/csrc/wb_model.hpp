@@ -27,6 +27,9 @@ struct LaneCfg {
     double ascale;       // multiplies the knot acceleration input
     int aunit;           // >=0: acceleration = e_aunit (ascale ignored)
     int tq, tv;          // tangent seed index into q or v (-1: none)
+    int l0 = 0, l1 = 4;  // legs this lane walks (a pass restricted to ONE leg is a per-leg TASK: its base wrench is a partial sum)
+    bool body = true;    // include the trunk's own inertial force (exactly one task per seed does)
+    bool partial = false; // true: hand the accumulated base wrench to sink.base() instead of running the base joints backward
 };
 
 // Outputs leave the pass through a SINK (sk.tau(i, value), sk.foot(l, pos, vel, acc)) that stores straight into LDS,
@@ -83,11 +86,11 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
     rev_joint<2>(c3, s3, Vv(3), Aa(3), om, vl, aa, al);
     rev_joint<1>(c4, s4, Vv(4), Aa(4), om, vl, aa, al);
     rev_joint<0>(c5, s5, Vv(5), Aa(5), om, vl, aa, al);
-    V3<S> nb, fb;
-    inertia_force<S>(ms, 3.3, 0, 0, 0, 0.011253, 0, 0, 0.036203, 0, 0.042673, om, vl, al, aa, nb, fb);
+    V3<S> nb = {S(0.0), S(0.0), S(0.0)}, fb = nb;
+    if (L.body) inertia_force<S>(ms, 3.3, 0, 0, 0, 0.011253, 0, 0, 0.036203, 0, 0.042673, om, vl, al, aa, nb, fb);
     V3<S> ob = {Q(0), Q(1), Q(2)};
 #pragma unroll 1
-    for (int l = 0; l < 4; l++) {
+    for (int l = L.l0; l < L.l1; l++) {
         const double sx = (l < 2) ? 1.0 : -1.0, sy = (l & 1) ? -1.0 : 1.0;
         const int j0 = 6 + 3 * l;
         S ca, sa, ch, sh, ck, sk;
@@ -149,6 +152,7 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
         fu = rot<0>(ca, sa, f1); nu = rot<0>(ca, sa, n1);
         fb = fb + fu; nb = nb + nu + ccross(sx * 0.19, sy * 0.049, 0.0, fu);
     }
+    if (L.partial) { out.base(fb, nb); return; }
     // backward through the base
     out.tau(5, nb.x);
     V3<S> f = rot<0>(c5, s5, fb), n = rot<0>(c5, s5, nb);
