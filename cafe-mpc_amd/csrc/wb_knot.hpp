@@ -507,11 +507,6 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int* rc = P.ref_contact + (size_t)k * 4; const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
     HS_PHASE(NT,
-        for (int e = tid; e < 432; e += NT) {
-            const int r = e / 36, c = e % 36;
-            D.JP()[e] = (c >= 3 && c < 18) ? L.Jall[r * 18 + c] : 0.0;
-            D.JW()[e] = (c < 18) ? L.dvel()[r * 18 + c] : L.Jall[r * 18 + c - 18];
-        }
         if (tid < 12) {
             const int f = tid / 3, a = tid % 3;
             double wpos = 0, wvel = 0;
@@ -528,8 +523,10 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
             D.ev[tid] = terminal ? L.fvel[tid] : (L.fvel[tid] - P.foot_vel[(size_t)k * 12 + tid]);
         })
 }
-// column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  added to out[0..35], and the gradient entry
-HD double wb_cost_column(WbDeriv& D, int d, double* colout /* stride 36 */) {
+// column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  written to out[0..35] (stride 36), and the gradient entry.  The blocks are
+// read in place:  JP = [0 | J(:,3:18) | 0] (position-type rows: base-translation and velocity columns zero, MHPCCost.cpp:54-59),
+// JW = [d(foot vel)/dq | J] (velocity-type rows)
+HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dvel, int d, double* colout /* stride 36 */) {
     // foot by foot; a foot's position-type rows (foot-place reg / swing pos) only touch columns 3..17, its velocity-type rows
     // (swing vel / touchdown vel) exist only for swing or touchdown feet: the activity tests are uniform over the wave, so
     // a stance knot skips the 36x36 velocity blocks entirely.
@@ -539,23 +536,25 @@ HD double wb_cost_column(WbDeriv& D, int d, double* colout /* stride 36 */) {
     double g = 0;
     for (int f = 0; f < 4; f++) {
         const double* wp = D.wp + 3 * f; const double* wv = D.wv + 3 * f;
+        const double* J0 = Jall + (3 * f) * 18; const double* J1 = J0 + 18; const double* J2 = J1 + 18;
         if (wp[0] != 0.0 || wp[1] != 0.0 || wp[2] != 0.0) {
-            const double* J0 = D.JP() + (3 * f) * 36; const double* J1 = J0 + 36; const double* J2 = J1 + 36;
-            const double t0 = wp[0] * J0[d], t1 = wp[1] * J1[d], t2 = wp[2] * J2[d];
+            const bool in = d >= 3 && d < 18; const int dd = in ? d : 3;
+            const double t0 = in ? wp[0] * J0[dd] : 0.0, t1 = in ? wp[1] * J1[dd] : 0.0, t2 = in ? wp[2] * J2[dd] : 0.0;
             g += t0 * D.ep[3 * f] + t1 * D.ep[3 * f + 1] + t2 * D.ep[3 * f + 2];
             _Pragma("unroll")
             for (int i = 3; i < 18; i++) acc[i] += J0[i] * t0 + J1[i] * t1 + J2[i] * t2;
         }
         if (wv[0] != 0.0 || wv[1] != 0.0 || wv[2] != 0.0) {
-            const double* J0 = D.JW() + (3 * f) * 36; const double* J1 = J0 + 36; const double* J2 = J1 + 36;
-            const double t0 = wv[0] * J0[d], t1 = wv[1] * J1[d], t2 = wv[2] * J2[d];
+            const double* V0 = dvel + (3 * f) * 18; const double* V1 = V0 + 18; const double* V2 = V1 + 18;
+            const int dd = d < 18 ? d : d - 18;
+            const double t0 = wv[0] * (d < 18 ? V0[dd] : J0[dd]), t1 = wv[1] * (d < 18 ? V1[dd] : J1[dd]), t2 = wv[2] * (d < 18 ? V2[dd] : J2[dd]);
             g += t0 * D.ev[3 * f] + t1 * D.ev[3 * f + 1] + t2 * D.ev[3 * f + 2];
             _Pragma("unroll")
-            for (int i = 0; i < 36; i++) acc[i] += J0[i] * t0 + J1[i] * t1 + J2[i] * t2;
+            for (int i = 0; i < 18; i++) { acc[i] += V0[i] * t0 + V1[i] * t1 + V2[i] * t2; acc[18 + i] += J0[i] * t0 + J1[i] * t1 + J2[i] * t2; }
         }
     }
     _Pragma("unroll")
-    for (int i = 0; i < 36; i++) colout[i * 36] += acc[i];
+    for (int i = 0; i < 36; i++) colout[i * 36] = acc[i];
     return g;
 }
 
@@ -627,12 +626,12 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
         size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
         if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
         D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
-    } for (int e = tid; e < 1296; e += NT) D.W[e] = 0.0;)
+    })
     HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
         double lxd = dt * P.q[d] * (L.x[d] - P.xr[(size_t)k * 36 + d]);
         double diag = dt * P.q[d];
-        lxd += wb_cost_column(D, d, D.W + d);
+        lxd += wb_cost_column(D, L.Jall, L.dvel(), d, D.W + d);
         // ReB fold on x (joint limits: x[6+i], height: x[2]) — rank-1 updates on the diagonal (ConstraintsBase.h:282-287)
         if (P.go_joint >= 0 && d >= 6 && d < 18) {
             const int i = d - 6;
@@ -685,11 +684,10 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     // d(J v)/dq with psi_kin at (q, v): kinematic lanes only
     wb_dpass<NT>(L, D, md, 0.0, 1.0, 1.0, 0.0, true);
     wb_cost_blocks<NT>(S, P, h, true);
-    HS_PHASE(NT, for (int e = tid; e < 1296; e += NT) D.W[e] = 0.0;)
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
         double px = P.qf[d] * (L.x[d] - P.xr[(size_t)h * 36 + d]);
-        px += wb_cost_column(D, d, D.W + d);
+        px += wb_cost_column(D, L.Jall, L.dvel(), d, D.W + d);
         double diag = P.qf[d];
         if (al_active && P.nt > 0) {   // compute_AL_partials (ConstraintsBase.h:412-425); hx[0:18] = J_foot,z (psi_dyn)
             int t = 0;
