@@ -277,13 +277,17 @@ template <int W, int N, int M, int PY>
 HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
     constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
-    constexpr int t1 = TN * TN, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
+    // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
+    // body), the symmetrisation step of the reference (SinglePhase.cpp:376) fills the rest
+    constexpr int t1 = TN * (TN + 1) / 2, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
     constexpr int NTL = (t3 - W + 3) / 4;
     if (NTL <= 0) return;
     MTile td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        if (t < t1) td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY};
+        int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
+        { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
+        if (t < t1) td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY};
         else if (t < t2) td[q] = MTile{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
         else td[q] = MTile{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY};
     }
@@ -356,7 +360,13 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         })
         SW_STAMP(4)
         HS_PHASE_L(NT,
-            if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) { const int i = e % N, j = e / N; if (i < j) { double s = (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2; CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s; } })
+            if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) {
+                const int i = e % N, j = e / N;
+                if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
+                    const double s = (i / 16 == j / 16) ? (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2 : CM(S.Qxx, i, j, LDN);
+                    CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s;
+                }
+            })
         SW_STAMP(5)
         if (!SWC.ok) return false;
         SW_STAMP(6)
