@@ -85,7 +85,7 @@ EXPORTS = ["hsddp_create", "hsddp_destroy", "hsddp_set_initial_condition", "hsdd
            "hsddp_hybrid_rollout", "hsddp_compute_cost", "hsddp_LQ_approximation", "hsddp_backward_sweep",
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
-           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_export_mpc_command", "hsddp_backend_name"]
+           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_backend_name"]
 
 
 def bind(lib):
@@ -113,6 +113,7 @@ def bind(lib):
     lib.hsddp_get_solve_time_ms.restype = C.c_float
     lib.hsddp_get_kernel_times.argtypes = [H, C.c_int, DP, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
     lib.hsddp_export_mpc_command.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
+    lib.hsddp_warm_start_phase.argtypes = [H, C.c_int, H, C.c_int, C.c_int]
     lib.hsddp_backend_name.argtypes = []
     lib.hsddp_backend_name.restype = C.c_char_p
     return lib
@@ -229,6 +230,10 @@ class Solver:
 
     def solve_time_ms(self):
         return float(self.lib.hsddp_get_solve_time_ms(self.h))
+
+    def warm_start_phase(self, dphase, src, sphase, shift):
+        """Receding-horizon shift of one phase's nominal trajectory from another solver of the same backend (device to device)."""
+        self._ck(self.lib.hsddp_warm_start_phase(self.h, dphase, src.h if src is not None else None, sphase, shift), "warm_start_phase")
 
     CMD_FIELDS = (("mpc_times", 1, "f"), ("torque", 12, "f"), ("eul", 3, "f"), ("pos", 3, "f"), ("qJ", 12, "f"), ("vWorld", 3, "f"),
                   ("eulrate", 3, "f"), ("qJd", 12, "f"), ("GRF", 12, "f"), ("feedback", 432, "f"), ("Qu", 12, "f"), ("Quu", 144, "f"),

@@ -143,73 +143,151 @@ def _approx_leq(a, b):
 
 
 # --------------------------------------------------------------------------------------------- MHPC problem
+class MHPCProblemData:
+    """Phase table of MHPCProblemData + the rules that evolve it: MHPCProblem::prepare_initialization (MHPCProblem.cpp:32-122)
+    and the receding-horizon update (update_WB_plan / update_SRB_plan, :252-397).  `describe()` emits the phase descriptors of
+    the current window; `update()` advances one MPC step and returns, per new phase, where every state / control slot comes
+    from in the previous window (what pop_front / push_back_default do to the Trajectory deques, TrajectoryManagement.cpp:130-228)."""
+
+    def __init__(self, ref, config, costs, cpar):
+        self.ref, self.cfg, self.costs, self.cpar = ref, config, costs, cpar
+        self.dt_wb, self.dt_srb = config["dt_wb"], config["dt_srb"]
+        self.ref.initialize(F32(config["plan_dur_wb"] + config["plan_dur_srb"]))
+        self.start, self.end, self.h, self.contact, self.dur, self.reach_end, self.has_td, self.shooting, self.uid = [], [], [], [], [], [], [], [], []
+        self._next_uid = 0
+        ref, cfg = self.ref, config
+        if cfg["plan_dur_wb"] > 1e-5:                                          # MHPCProblem.cpp:69-108
+            t = F32(0); start = F32(0)
+            c_prev = ref.contact_at(t); d_prev = ref.at(t)["status_dur"].copy()
+            while _approx_leq(t, cfg["plan_dur_wb"]):
+                c_cur = ref.contact_at(t)
+                if (c_cur != c_prev).any() or _approx_eq(t, cfg["plan_dur_wb"]):
+                    end = t
+                    self._push_phase(start, end, int(round(float(F32(end - start)) / self.dt_wb)), c_prev.copy(), d_prev.copy(), shooting=1)
+                    self.reach_end[-1] = False      # (contact_prev != contact_prev).any(): always false (quirk viii)
+                    c_prev = c_cur; d_prev = ref.at(t)["status_dur"].copy(); start = end
+                t = F32(float(t) + self.dt_wb)
+        self.srb_h = int(round(cfg["plan_dur_srb"] / self.dt_srb)) if cfg["plan_dur_srb"] > 1e-5 else 0
+        self.srb_start = F32(cfg["plan_dur_wb"])
+        for i in range(len(self.h)):                                           # add_tconstr_one_phase at initialisation (:198)
+            self.has_td[i] = bool(self._touchdown(i).any())
+        self.ref_start = F32(0)                                                # QuadReference::get_start_time
+
+    def _push_phase(self, start, end, h, contact, dur, shooting):
+        self.start.append(F32(start)); self.end.append(F32(end)); self.h.append(h); self.contact.append(contact); self.dur.append(dur)
+        self.reach_end.append(False); self.has_td.append(False); self.shooting.append(shooting); self.uid.append(self._next_uid); self._next_uid += 1
+
+    def _next_contact(self, i):                                                # update_resetmap / add_tconstr_one_phase (:524-540, 560-580)
+        if i + 1 < len(self.h):
+            return self.contact[i + 1]
+        return self.ref.contact_at(F32(self.cfg["plan_dur_wb"] + float(self.cfg["dt_mpc"])))
+
+    def _touchdown(self, i):
+        nxt = self._next_contact(i)
+        return np.array([1 if (self.contact[i][l] == 0 and nxt[l] == 1) else 0 for l in range(4)])
+
+    # ---- receding-horizon update: one MPC step -----------------------------------------------------------
+    def update(self):
+        """MHPCProblem::update (:252-268).  Returns the slot maps {uid: (front_popped, pushed)} of surviving phases."""
+        cfg, ref = self.cfg, self.ref
+        old = {u: dict(h=h) for u, h in zip(self.uid, self.h)}
+        nsteps = int(round(float(cfg["dt_mpc"]) / self.dt_wb))
+        for _ in range(int(np.floor(float(cfg["dt_mpc"]) / float(ref.dt) + 1e-6)) if False else 0):
+            pass
+        k_before = ref.k_cur
+        ref.step(cfg["dt_mpc"])
+        self.ref_start = F32(float(self.ref_start) + (ref.k_cur - k_before) * float(ref.dt))
+        popped = {u: 0 for u in self.uid}; pushed = {u: 0 for u in self.uid}
+        if cfg["plan_dur_wb"] > 0:                                             # update_WB_plan (:271-352)
+            new_start_time = self.ref_start
+            for _ in range(nsteps):
+                first = F32(float(self.start[0]) + self.dt_wb)
+                if _approx_eq(self.end[0], first):
+                    for lst in (self.start, self.end, self.h, self.contact, self.dur, self.reach_end, self.has_td, self.shooting, self.uid):
+                        lst.pop(0)
+                else:
+                    popped[self.uid[0]] += 1; self.h[0] -= 1; self.start[0] = first
+            for _ in range(nsteps):
+                new_end = F32(float(self.end[-1]) + self.dt_wb)
+                t_rel = F32(new_end - new_start_time)
+                new_contact = ref.contact_at(t_rel)
+                change = bool((new_contact != self.contact[-1]).any())
+                if change and self.reach_end[-1]:
+                    self._push_phase(self.end[-1], new_end, 1, new_contact.copy(), ref.at(t_rel)["status_dur"].copy(), shooting=0)   # SS_set empty
+                    popped[self.uid[-1]] = 0; pushed[self.uid[-1]] = 0
+                else:
+                    self.end[-1] = new_end; self.h[-1] += 1
+                    if change:
+                        self.reach_end[-1] = True; self.has_td[-1] = bool(self._touchdown(len(self.h) - 1).any())
+                    pushed[self.uid[-1]] += 1
+            n = len(self.h)
+            for i in range(n):                                                 # "other updates" (:340-351)
+                if i < n - 1 or self.h[i] > nsteps:
+                    self.shooting[i] = 1
+        if cfg["plan_dur_srb"] > 0:                                            # update_SRB_plan (:355-377): nsteps = floor(dt_mpc / dt_srb) pop/push pairs
+            self.srb_steps = int(np.floor(float(cfg["dt_mpc"]) / self.dt_srb + 1e-6))
+            self.srb_start = F32(float(self.ref_start) + cfg["plan_dur_wb"])
+        return {u: (popped[u], pushed[u], old[u]["h"] if u in old else None) for u in self.uid}
+
+    # ---- descriptors of the current window --------------------------------------------------------------------
+    def describe(self, ubar_mode="zero"):
+        cfg, ref, costs, cpar = self.cfg, self.ref, self.costs, self.cpar
+        dt_wb, dt_srb = self.dt_wb, self.dt_srb
+        n_wb = len(self.h)
+        phases = []
+        for i in range(n_wb):
+            h = self.h[i]
+            nxt = self._next_contact(i)
+            t_off = float(F32(self.start[i] - self.start[0]))
+            xr = np.zeros((h + 1, 36)); ur = np.zeros((h + 1, 12)); yr = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); fv = np.zeros((h + 1, 12))
+            bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32); X0 = np.zeros((h + 1, 36))
+            for k in range(h + 1):
+                a = ref.at(F32(t_off + k * dt_wb))                             # cost / constraint lookups at t_offset + k dt (SinglePhase.cpp:243,298)
+                b = a["body_state"]
+                xr[k] = np.concatenate([b[:6], a["jnt_angle"], b[6:], a["jnt_vel"]])  # WBReference::get_reference_at_t (MHPCReference.cpp:24-39)
+                ur[k] = a["torque"]; yr[k] = a["grf"]; fp[k] = a["foot_placements"]; fv[k] = a["foot_velocities"]; bp[k] = b[:3]; rc[k] = a["contact"]
+                a0 = ref.at(F32(float(F32(self.start[i] - self.ref_start)) + k * dt_wb))   # initial guess lookup (MHPCProblem.cpp:186-193)
+                b0 = a0["body_state"]
+                X0[k] = np.concatenate([b0[:6], a0["jnt_angle"], b0[6:], a0["jnt_vel"]])
+            refs = dict(xr=xr, ur=ur, yr=yr, foot_pos=fp, foot_vel=fv, body_pos=bp, ref_contact=rc)
+            last = i == n_wb - 1
+            ph = problems.wb_phase(h, dt_wb, t_off, self.contact[i], nxt, refs, next_model=MODEL_SRB if (last and self.srb_h > 0) else MODEL_WB,
+                                   bg_alpha=cfg["BG_alpha"], shooting=self.shooting[i], ubar_mode="zero")
+            d = ph["desc"]
+            problems._set(d.q, costs["wb_q"]); problems._set(d.r, costs["wb_r"]); problems._set(d.qf, costs["wb_qf"])
+            problems._set(d.w_foot_reg, costs["foot_reg"]); problems._set(d.w_swing_pos, costs["swing_pos"]); problems._set(d.w_swing_vel, costs["swing_vel"])
+            d.reb_torque, d.reb_joint, d.reb_minheight, d.reb_grf, d.al_td = cpar["torque"], cpar["joint"], cpar["minheight"], cpar["grf"], cpar["td"]
+            if not self.has_td[i]:                                             # no WBTouchDown / TDVelocityPenalty object on this phase (yet)
+                d.c_touchdown = 0; d.w_td_vel = -1.0
+            ph["Xbar"] = X0; ph["uid"] = self.uid[i]
+            if ubar_mode == "gravity_comp":
+                ph["Ubar"][:] = problems.wb_gravity_comp_torque(X0[0, :18], self.contact[i])
+            phases.append(ph)
+        if self.srb_h > 0:                                                     # MHPCProblem.cpp:216-247, 488-521
+            h = self.srb_h; t_off = float(F32(self.srb_start - self.ref_start))
+            xr = np.zeros((h + 1, 12)); ur = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); rc = np.zeros((h + 1, 4), dtype=np.int32); bp = np.zeros((h + 1, 3))
+            for k in range(h + 1):
+                a = ref.at(F32(t_off + k * dt_srb))
+                xr[k] = a["body_state"]; ur[k] = a["grf"]; fp[k] = a["foot_placements"]; rc[k] = a["contact"]; bp[k] = a["body_state"][:3]
+            ph = problems.srb_phase(h, dt_srb, t_off, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
+            d = ph["desc"]
+            problems._set(d.q, costs["srb_q"]); problems._set(d.r, costs["srb_r"]); problems._set(d.qf, costs["srb_qf"])
+            d.reb_minheight = cpar["minheight"]
+            ph["Xbar"] = xr.copy(); ph["uid"] = -1
+            if ubar_mode == "gravity_comp":
+                ph["Ubar"] = ur[:h].copy()
+            phases.append(ph)
+        info = dict(start_times=[float(s) for s in self.start], end_times=[float(e) for e in self.end], horizons=list(self.h),
+                    contacts=[np.asarray(c).tolist() for c in self.contact], shooting=list(self.shooting), has_td=list(self.has_td),
+                    status_durations=np.array(self.dur, dtype=np.float32) if self.dur else np.zeros((0, 4), np.float32), srb_horizon=self.srb_h,
+                    x0=phases[0]["Xbar"][0].copy())
+        return phases, info
+
+
 def build_mhpc_problem(ref, config, costs, cpar, ubar_mode="zero"):
-    """MHPCProblem::prepare_initialization + initialize_multiPhaseProblem at the current reference time.
+    """MHPCProblem::prepare_initialization + initialize_multiPhaseProblem at the start of the reference.
     Returns (phases, info) where info holds the phase table of MHPCProblemData (start/end times, horizons, contacts, durations)."""
-    dt_wb, dt_srb = config["dt_wb"], config["dt_srb"]
-    plan_all = F32(config["plan_dur_wb"] + config["plan_dur_srb"])
-    ref.initialize(plan_all)
-    starts, ends, hors, contacts, durs = [], [], [], [], []
-    if config["plan_dur_wb"] > 1e-5:                                          # MHPCProblem.cpp:69-108
-        t = F32(0); start = F32(0)
-        c_prev = ref.contact_at(t); d_prev = ref.at(t)["status_dur"].copy()
-        while _approx_leq(t, config["plan_dur_wb"]):
-            c_cur = ref.contact_at(t)
-            if (c_cur != c_prev).any() or _approx_eq(t, config["plan_dur_wb"]):
-                end = t
-                starts.append(start); ends.append(end); hors.append(int(round(float(F32(end - start)) / dt_wb)))
-                contacts.append(c_prev.copy()); durs.append(d_prev.copy())
-                c_prev = c_cur; d_prev = ref.at(t)["status_dur"].copy(); start = end
-            t = F32(float(t) + dt_wb)
-    n_wb = len(starts)
-    srb_h = int(round(config["plan_dur_srb"] / dt_srb)) if config["plan_dur_srb"] > 1e-5 else 0
-    srb_start = F32(config["plan_dur_wb"])
-    phases = []
-    for i in range(n_wb):
-        h = hors[i]
-        nxt = contacts[i + 1] if i + 1 < n_wb else ref.contact_at(F32(config["plan_dur_wb"] + float(config["dt_mpc"])))   # :532-540
-        t_off = float(F32(starts[i] - starts[0]))
-        xr = np.zeros((h + 1, 36)); ur = np.zeros((h + 1, 12)); yr = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); fv = np.zeros((h + 1, 12))
-        bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32); X0 = np.zeros((h + 1, 36))
-        for k in range(h + 1):
-            a = ref.at(F32(t_off + k * dt_wb))                                 # cost / constraint lookups at t_offset + k dt (SinglePhase.cpp:243,298)
-            b = a["body_state"]
-            xr[k] = np.concatenate([b[:6], a["jnt_angle"], b[6:], a["jnt_vel"]])      # WBReference::get_reference_at_t (MHPCReference.cpp:24-39)
-            ur[k] = a["torque"]; yr[k] = a["grf"]; fp[k] = a["foot_placements"]; fv[k] = a["foot_velocities"]; bp[k] = b[:3]; rc[k] = a["contact"]
-            a0 = ref.at(F32(float(starts[i]) + k * dt_wb))                     # initial guess lookup (MHPCProblem.cpp:186-193)
-            b0 = a0["body_state"]
-            X0[k] = np.concatenate([b0[:6], a0["jnt_angle"], b0[6:], a0["jnt_vel"]])
-        refs = dict(xr=xr, ur=ur, yr=yr, foot_pos=fp, foot_vel=fv, body_pos=bp, ref_contact=rc)
-        last = i == n_wb - 1
-        ph = problems.wb_phase(h, dt_wb, t_off, contacts[i], nxt, refs, next_model=MODEL_SRB if (last and srb_h > 0) else MODEL_WB,
-                               bg_alpha=config["BG_alpha"], ubar_mode="zero")
-        d = ph["desc"]
-        problems._set(d.q, costs["wb_q"]); problems._set(d.r, costs["wb_r"]); problems._set(d.qf, costs["wb_qf"])
-        problems._set(d.w_foot_reg, costs["foot_reg"]); problems._set(d.w_swing_pos, costs["swing_pos"]); problems._set(d.w_swing_vel, costs["swing_vel"])
-        d.reb_torque, d.reb_joint, d.reb_minheight, d.reb_grf, d.al_td = cpar["torque"], cpar["joint"], cpar["minheight"], cpar["grf"], cpar["td"]
-        ph["Xbar"] = X0
-        if ubar_mode == "gravity_comp":
-            ph["Ubar"][:] = problems.wb_gravity_comp_torque(X0[0, :18], contacts[i])
-        phases.append(ph)
-    if srb_h > 0:                                                              # MHPCProblem.cpp:216-247, 488-521
-        h = srb_h; t_off = float(srb_start)
-        xr = np.zeros((h + 1, 12)); ur = np.zeros((h + 1, 12)); fp = np.zeros((h + 1, 12)); rc = np.zeros((h + 1, 4), dtype=np.int32); bp = np.zeros((h + 1, 3))
-        X0 = np.zeros((h + 1, 12))
-        for k in range(h + 1):
-            a = ref.at(F32(t_off + k * dt_srb))
-            xr[k] = a["body_state"]; ur[k] = a["grf"]; fp[k] = a["foot_placements"]; rc[k] = a["contact"]; bp[k] = a["body_state"][:3]
-            X0[k] = ref.at(F32(float(srb_start) + k * dt_srb))["body_state"]
-        ph = problems.srb_phase(h, dt_srb, t_off, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
-        d = ph["desc"]
-        problems._set(d.q, costs["srb_q"]); problems._set(d.r, costs["srb_r"]); problems._set(d.qf, costs["srb_qf"])
-        d.reb_minheight = cpar["minheight"]
-        ph["Xbar"] = X0
-        if ubar_mode == "gravity_comp":
-            ph["Ubar"] = ur[:h].copy()
-        phases.append(ph)
-    info = dict(start_times=[float(s) for s in starts], end_times=[float(e) for e in ends], horizons=hors, contacts=[c.tolist() for c in contacts],
-                status_durations=np.array(durs, dtype=np.float32) if durs else np.zeros((0, 4), np.float32), srb_horizon=srb_h, x0=phases[0]["Xbar"][0].copy())
-    return phases, info
+    return MHPCProblemData(ref, config, costs, cpar).describe(ubar_mode=ubar_mode)
 
 
 def build_from_tree(root, gait=None, ubar_mode="zero"):
@@ -234,3 +312,21 @@ def load_ddp_setting(path):
                             dynamics_feas_thresh=float(d["dynamics_feas_thresh"]), merit_rho=float(d["merit_rho"]), merit_scale=float(d["merit_scale"]),
                             merit_offset=float(d["merit_offset"]), AL_active=tf(d["AL_active"]), ReB_active=tf(d["ReB_active"]), MS=tf(d["MS"]),
                             nsteps_per_node=int(d["nsteps_per_node"]))
+
+
+def shift_solver(solver_cls, lib, old_solver, old_phases, pd, slot_map, ubar_mode="zero", **solver_kw):
+    """One receding-horizon step on the solver side (what MHPCLocomotion::update, MHPC/MHPCLocomotion.cpp:109-122, gets from
+    MHPCProblem::update): build the solver of the shifted window and move the nominal trajectories over, device to device.
+    `slot_map` is the return value of pd.update().  Returns (new_solver, new_phases, info)."""
+    phases, info = pd.describe(ubar_mode=ubar_mode)
+    new = solver_cls(lib, phases, batch=old_solver.batch, **solver_kw)
+    old_index = {p.get("uid"): i for i, p in enumerate(old_phases)}
+    for i, p in enumerate(phases):
+        uid = p.get("uid")
+        if uid == -1:                                  # SRB tail: update_SRB_plan pops/pushes floor(dt_mpc/dt_srb) knots (0 for the shipped config)
+            new.warm_start_phase(i, old_solver, old_index[-1], getattr(pd, "srb_steps", 0))
+        elif uid in old_index:
+            new.warm_start_phase(i, old_solver, old_index[uid], slot_map[uid][0])
+        else:
+            new.warm_start_phase(i, None, -1, 0)       # phase created by the update: zero trajectory (Trajectory constructor)
+    return new, phases, info

@@ -67,8 +67,16 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, in
         else srb_rollout_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b, eps, so, slot);
         return;
     }
+    if (!P.shooting) return;     // a phase without shooting nodes is rolled sequentially by the wave of its predecessor's terminal knot
     if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-    else wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
+    else {
+        wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
+        for (int pj = pi + 1; pj < nph && !ph[pj].shooting; pj++) {      // single-shooting chain (young phases of the receding-horizon update)
+            const PhaseDev& Q = ph[pj]; const size_t s0 = (size_t)b * nslots + Q.slot0;
+            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
+            wb_rollout_terminal<64>(L, Q, pj + 1 < nph ? &ph[pj + 1] : nullptr, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
@@ -151,6 +159,23 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph, i
     linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
     __syncthreads();
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
+}
+
+// receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase): one workgroup per (problem, destination knot)
+__global__ void __launch_bounds__(256) k_warm_start(PhaseDev D, PhaseDev S, int has_src, int shift) {
+    const int b = blockIdx.y, k = blockIdx.x, n = D.n, m = D.m, tid = threadIdx.x;
+    const size_t dx = ((size_t)b * (D.h + 1) + k) * n, du = ((size_t)b * D.h + k);
+    const int ks = k + shift;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double v = 0.0;
+        if (has_src) v = (ks <= S.h) ? S.Xbar[((size_t)b * (S.h + 1) + ks) * n + i] : S.X[((size_t)b * (S.h + 1) + S.h) * n + i];
+        D.Xbar[dx + i] = v; D.X[dx + i] = v; D.dX[dx + i] = 0.0;
+    }
+    if (k < D.h) {
+        const bool cs = has_src && ks < S.h; const size_t su = (size_t)b * S.h + ks;
+        for (int i = tid; i < m; i += blockDim.x) { const double v = cs ? S.Ubar[su * m + i] : 0.0; D.Ubar[du * m + i] = v; D.U[du * m + i] = v; D.dU[du * m + i] = 0.0; }
+        for (int i = tid; i < m * n; i += blockDim.x) D.K[du * m * n + i] = cs ? S.K[su * m * n + i] : 0.0;
+    }
 }
 
 // MHPC_Command_lcmt packing (include/hsddp.h): one workgroup per control step, fp64 -> fp32 on the device
@@ -394,7 +419,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     for (int i = 0; i < n_phases; i++) {
         if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB && phases[i].model != HSDDP_MODEL_HKD) return HSDDP_EINVAL;
         if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) { fprintf(stderr, "[hsddp_hip] phase %d: the reference has no reset map from model %d to model %d (MHPCReset.cpp:4-52, HKDReset.h)\n", i, phases[i - 1].model, phases[i].model); return HSDDP_ENOTSUP; }
-        if (!phases[i].shooting) { fprintf(stderr, "[hsddp_hip] single-shooting phases are not supported (knot-parallel multiple shooting only)\n"); return HSDDP_ENOTSUP; }
+        if (!phases[i].shooting && (i == 0 || phases[i].model != HSDDP_MODEL_WB)) { fprintf(stderr, "[hsddp_hip] phase %d: a phase without shooting nodes must be a whole-body phase behind another phase (the young phases of MHPCProblem::update)\n", i); return HSDDP_ENOTSUP; }
         if (phases[i].horizon <= 0) return HSDDP_EINVAL;
     }
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { fprintf(stderr, "[hsddp_hip] no HIP device %d\n", device); return HSDDP_ENODEV; }
@@ -616,6 +641,18 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     return HSDDP_OK;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h ? h->solve_ms : 0.f; }
+
+int hsddp_warm_start_phase(hsddp_handle_t* dst, int dphase, hsddp_handle_t* src, int sphase, int shift) {
+    if (!dst || dphase < 0 || dphase >= dst->nph || shift < 0) return HSDDP_EINVAL;
+    const PhaseDev& D = dst->ph[dphase];
+    const bool has = src != nullptr && sphase >= 0;
+    if (has && (sphase >= src->nph || src->batch != dst->batch || src->device != dst->device || src->ph[sphase].model != D.model)) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(dst->device));
+    if (has) HIPCK(hipStreamSynchronize(src->stream));
+    hipLaunchKernelGGL(k_warm_start, dim3(D.h + 1, dst->batch), dim3(256), 0, dst->stream, D, has ? src->ph[sphase] : D, has ? 1 : 0, shift);
+    HIPCK(hipStreamSynchronize(dst->stream));
+    return HSDDP_OK;
+}
 
 int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double mpc_time, double dt, const float* status_times, unsigned int* out) {
     if (!h || problem < 0 || problem >= h->batch || n_steps <= 0 || !out) return HSDDP_EINVAL;

@@ -36,6 +36,7 @@ struct WbCore {
     HD double* dacc() { return GG; }          // LQ program: [3f+r][18] tangents of the foot accelerations
     HD double* dvel() { return GG + 216; }    // LQ program: [3f+r][18] tangents of the foot velocities (= footVelPartialDq)
     double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64], rdM[18], rdG[12];
+    double xnext[36];                  // single-shooting chain: the state handed from one knot to the next inside the wave
     unsigned long long tstamp;
 };
 struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (see accessors)
@@ -391,12 +392,14 @@ struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // 
 // Rollout of one knot k < h of problem b.   eps: line-search step.
 template <int NT>
 HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b, int k, double eps, int reb_active,
-                        const double* x0, SlotOut so, size_t slot, int* fail_flag) {
+                        const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+    // ss: knot of a phase WITHOUT shooting nodes (SS_set empty, a phase the receding-horizon update has just created,
+    // MHPCProblem.cpp:340-351): X[k] is the simulated state handed over in L.xnext, X[k+1] = Xsim[k+1], the defect is zero
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12;
     double* Kst = L.Jc();   // 432 doubles: [Jc | Xm] are free until the contact solve
     HS_PHASE(NT, if (tid < 36) {
-        double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid];
+        double xb = P.Xbar[kx + tid], x = ss ? L.xnext[tid] : xb + eps * P.dX[kx + tid];
         L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
     } if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
       for (int i = tid; i < 432; i += NT) Kst[i] = P.K[((size_t)b * h + k) * 432 + i];)
@@ -411,8 +414,9 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
     HS_PHASE(NT, if (tid < 36) {
         double xs = (tid < 18) ? L.x[tid] + L.x[18 + tid] * P.dt : L.x[tid] + L.qdd[tid - 18] * P.dt;
         P.Xsim[kx + 36 + tid] = xs;
-        double xn = P.Xbar[kx + 36 + tid] + eps * P.dX[kx + 36 + tid];
+        double xn = ss ? xs : P.Xbar[kx + 36 + tid] + eps * P.dX[kx + 36 + tid];
         double d = xs - xn; P.Defect[kx + 36 + tid] = d;
+        if (ss) { L.xnext[tid] = xs; if (k == 0) { P.Xsim[kx + tid] = L.x[tid]; P.Defect[kx + tid] = 0.0; } }
         double dsq = d * d, nsq = xs * xs;
         if (x0 != nullptr && k == 0) { double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
         L.red[tid] = dsq; L.tmp[tid] = nsq;
@@ -457,10 +461,10 @@ HD double wb_terminal_cost_base(const PhaseDev& P, const WbCore& L) {
 // Terminal knot (k = h) of a phase: terminal constraint + cost, then the reset map into the next phase.
 template <int NT>
 HD void wb_rollout_terminal(WbCore& L, const PhaseDev& P, const PhaseDev* Pn, const ModelDev& md, int b, double eps, int al_active,
-                            SlotOut so, size_t slot) {
+                            SlotOut so, size_t slot, bool ss = false) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 36;
-    HS_PHASE(NT, if (tid < 36) { double x = P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; }
+    HS_PHASE(NT, if (tid < 36) { double x = ss ? L.xnext[tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; }
              if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;)
     const bool impact = (Pn != nullptr) && P.has_impact;
     wb_terms<NT>(L, md, impact);
@@ -489,8 +493,9 @@ HD void wb_rollout_terminal(WbCore& L, const PhaseDev& P, const PhaseDev* Pn, co
         if (nn == 36) xi = (tid < 18) ? L.x[tid] : L.qdd[tid - 18];
         else xi = (tid < 6) ? L.x[tid] : L.qdd[tid - 6];          // StateProjection: x[0:6], x[18:24] (MHPCReset.h:24-26)
         Pn->Xsim[nx + tid] = xi;
-        double d = xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);
+        double d = Pn->shooting ? xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]) : 0.0;     // no shooting node at the start of a young phase: X[0] = x_init
         Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
+        if (nn == 36) L.xnext[tid] = xi;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < nn; i++) s += L.red[i]; so.dsq[slot] = s; })
 }

@@ -162,6 +162,14 @@ float hsddp_get_solve_time_ms(hsddp_handle_t *h);
  * and number of launches; names returned as a NUL-separated list. Optional for the CPU backend. */
 int hsddp_get_kernel_times(hsddp_handle_t *h, int max_n, double *ms, long long *launches, char *names, int names_cap);
 
+/* -- receding-horizon warm start (MHPCProblem::update, MHPCProblem.cpp:252-397): the phase `dphase` of handle `dst` takes its
+ * nominal trajectory from phase `sphase` of handle `src` the way SinglePhase::pop_front / push_back_default shift the
+ * Trajectory deques (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228), device to device:
+ *   state   k <- Xbar_src[k + shift]              for k + shift <= h_src, else X_src[h_src]   (push_back_state(X.back()))
+ *   control k <- Ubar_src[k + shift], K_src[..]   for k + shift <  h_src, else 0
+ * sphase < 0: a phase created by the update (zero trajectory).  Same model and batch on both sides. */
+int hsddp_warm_start_phase(hsddp_handle_t *dst, int dphase, hsddp_handle_t *src, int sphase, int shift);
+
 /* -- policy export in the field order of lcmtypes/MHPC_Command_lcmt.lcm, filled the way MHPCLocomotion::publish_mpc_cmd does
  * (MHPC/MHPCLocomotion.cpp:190-287): the first n_steps control knots of problem `problem`, walking the whole-body phases in
  * order, everything cast to fp32, matrices column-major (Eigen .data()).  `out` receives 32-bit words (host byte order; LCM's

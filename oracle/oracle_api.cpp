@@ -123,6 +123,28 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h->s.solve_ms; }
+// SinglePhase::pop_front x shift + push_back_default for the rest (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228)
+int hsddp_warm_start_phase(hsddp_handle_t* dst, int dphase, hsddp_handle_t* src, int sphase, int shift) {
+    if (!dst || dphase < 0 || dphase >= (int)dst->s.ph.size() || shift < 0) return HSDDP_EINVAL;
+    const bool has = src != nullptr && sphase >= 0;
+    if (has && (sphase >= (int)src->s.ph.size() || src->s.batch != dst->s.batch || src->s.ph[sphase].d.model != dst->s.ph[dphase].d.model)) return HSDDP_EINVAL;
+    const PhaseDef& PD = dst->s.ph[dphase]; const int n = PD.n, m = PD.m, hd = PD.h;
+    for (int b = 0; b < dst->s.batch; b++) {
+        Traj& D = dst->s.pb[b].tr[dphase];
+        const Traj* S = has ? &src->s.pb[b].tr[sphase] : nullptr; const int hs = has ? src->s.ph[sphase].h : 0;
+        for (int k = 0; k <= hd; k++) for (int i = 0; i < n; i++) {
+            const int ks = k + shift; double v = 0.0;
+            if (has) v = (ks <= hs) ? S->Xbar[(size_t)ks * n + i] : S->X[(size_t)hs * n + i];
+            D.Xbar[(size_t)k * n + i] = v; D.X[(size_t)k * n + i] = v; D.dX[(size_t)k * n + i] = 0.0;
+        }
+        for (int k = 0; k < hd; k++) {
+            const int ks = k + shift; const bool cs = has && ks < hs;
+            for (int i = 0; i < m; i++) { const double v = cs ? S->Ubar[(size_t)ks * m + i] : 0.0; D.Ubar[(size_t)k * m + i] = v; D.U[(size_t)k * m + i] = v; D.dU[(size_t)k * m + i] = 0.0; }
+            for (int i = 0; i < m * n; i++) D.K[(size_t)k * m * n + i] = cs ? S->K[(size_t)ks * m * n + i] : 0.0;
+        }
+    }
+    return 0;
+}
 // MHPCLocomotion::publish_mpc_cmd (MHPC/MHPCLocomotion.cpp:190-287) restated: field order of MHPC_Command_lcmt.lcm, fp32 casts
 int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double mpc_time, double dt, const float* status_times, unsigned int* out) {
     if (!h || problem < 0 || problem >= h->s.batch || n_steps <= 0 || !out) return HSDDP_EINVAL;

@@ -78,8 +78,16 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
             } else if (P.model == HSDDP_MODEL_SRB) {
                 if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
                 else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot);
-            } else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
-            else wb_rollout_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, eps, o.AL_active, so, slot);
+            } else if (!P.shooting) continue;
+            else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+            else {
+                wb_rollout_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, eps, o.AL_active, so, slot);
+                for (int pj = pi + 1; pj < h->nph && !h->ph[pj].shooting; pj++) {
+                    const PhaseDev& Q = h->ph[pj]; const size_t s0 = (size_t)b * h->nslots + Q.slot0;
+                    for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, h->md, b, kq, eps, o.ReB_active, nullptr, so, s0 + kq, h->fail.data(), true);
+                    wb_rollout_terminal<64>(L, Q, pj + 1 < h->nph ? &h->ph[pj + 1] : nullptr, h->md, b, eps, o.AL_active, so, s0 + Q.h, true);
+                }
+            }
         }
         double c = 0, d = 0; for (int s = 0; s < h->nslots; s++) { c += h->cost[(size_t)b * h->nslots + s]; d += h->dsq[(size_t)b * h->nslots + s]; }
         h->acost[b] = c; h->feas[b] = sqrt(d);
@@ -125,5 +133,6 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
 int hsddp_export_mpc_command(hsddp_handle_t*, int, int, double, double, const float*, unsigned int*) { return HSDDP_ENOTSUP; }
+int hsddp_warm_start_phase(hsddp_handle_t*, int, hsddp_handle_t*, int, int) { return HSDDP_ENOTSUP; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
 }

@@ -7,7 +7,7 @@ import shutil
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cafe_tree")
-N = 90   # samples kept: plan horizon 0.75 s at dt = 0.01 needs 77
+N = 130   # samples kept: plan horizon 0.75 s at dt = 0.01 needs 77, plus 0.5 s of receding-horizon shifts
 
 
 def trim(src, dst, n):

@@ -15,7 +15,7 @@ TREE = os.path.join(ROOT, "tests", "golden", "cafe_tree")
 
 def test_quad_reference_loader_semantics():
     ref = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"))
-    assert len(ref) == 90 and ref.dt == np.float32(0.01)
+    assert len(ref) == 130 and ref.dt == np.float32(0.01)
     # std::stof parsing: values are float32 numbers widened to double (QuadReference.cpp:170-332)
     bs = ref.tp["body_state"]
     assert np.array_equal(bs, bs.astype(np.float32).astype(np.float64))

@@ -121,6 +121,42 @@ def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, gait):
     assert cmd["N_mpcsteps"] == 8 and np.isfinite(cmd["feedback"]).all()
 
 
+def test_receding_horizon_loop_parity(hip_lib, oracle_lib):
+    """The MPC loop of testTrajOptInLoop.cpp:85-117 in shape: solve, then per tick MHPCProblem::update (phase table shift incl. the
+    young single-shooting phases), warm start moved device to device (hsddp_warm_start_phase), runtime iteration limits.  GPU and
+    oracle run the same loop; every tick's solve must agree."""
+    import importlib, os
+    from conftest import ROOT
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    cfg = builder.load_mhpc_config(tree + "/MHPC/settings/mhpc_config.info")
+    pd = builder.MHPCProblemData(builder.QuadReference(tree + "/Reference/Data/bound/quad_reference.csv"), cfg,
+                                 builder.load_cost_weights(tree + "/" + cfg["costFile"]), builder.load_constraint_params(tree + "/" + cfg["constraintParamFile"]))
+    opt0 = builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")
+    opt_rt = builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")
+    opt_rt.max_AL_iter, opt_rt.max_DDP_iter = opt_rt.max_AL_iter_runtime, opt_rt.max_DDP_iter_runtime       # MHPCLocomotion.cpp:113-115
+    phases, info = pd.describe(ubar_mode="gravity_comp")
+    x0 = np.vstack([info["x0"], info["x0"] + 0.005 * (pkg.problems.wb_ensemble_x0(1, 3)[0] - pkg.problems.wb_nominal_state())])
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt0); sg.solve(opt0)
+    pc.compare_solve(so, sg, len(phases), rtol=1e-5)
+    seen_young = False
+    for tick in range(1, 8):
+        m = pd.update()
+        nst = int(round(float(cfg["dt_mpc"]) / cfg["dt_wb"]))
+        xg = sg.field(0, "XBAR")        # predicted state after one MPC step = next initial condition (same vector for both backends)
+        x0n = xg[:, nst] if xg.shape[1] > nst else sg.field(1, "XBAR")[:, nst - xg.shape[1] + 1]
+        so2, ph2, inf2 = builder.shift_solver(pkg.Solver, oracle_lib, so, phases, pd, m)
+        sg2, _, _ = builder.shift_solver(pkg.Solver, hip_lib, sg, phases, pd, m)
+        seen_young |= 0 in inf2["shooting"]
+        for s2 in (so2, sg2):
+            s2.set_initial_condition(np.ascontiguousarray(x0n)); s2.solve(opt_rt)
+        pc.compare_solve(so2, sg2, len(ph2), rtol=1e-5)
+        assert sum(inf2["horizons"]) == 25
+        so.close(); sg.close(); so, sg, phases = so2, sg2, ph2
+    assert seen_young
+
+
 def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib):
     """BarrelRollTO.cpp as shipped: 6 hybrid phases / 125 knots (stance, right-side stance, flight, landing, flight, stance),
     zero-torque start, br_ddp_setting.info; the first AL iteration (10 DDP iterations, line searches down to small steps)."""

@@ -19,7 +19,7 @@ def emu_lib():
     return pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu.so")))
 
 
-@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll", "hkd"])
+@pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll", "hkd", "mpc_tick"])
 def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
     if which == "mhpc":    # whole-body phases + single-rigid-body tail: mixed state dimension across the phase boundary
         phases = pkg.problems.mhpc_problem(wb_horizons=(4, 3), srb_horizons=(3, 2))
@@ -34,6 +34,17 @@ def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
         phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.03, 0.06, 0.10, 0.13, 0.16, 0.19))
         x0 = np.vstack([xinit, xinit + 0.01 * (x0[0] - pkg.problems.wb_nominal_state())])
         opt = pkg.problems.br_ddp_setting()
+    if which == "mpc_tick":      # window after one receding-horizon update: a young single-shooting phase (h = 1) in front of the SRB tail
+        import importlib, os
+        builder = importlib.import_module(pkg.__name__ + ".builder")
+        tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+        cfg = builder.load_mhpc_config(tree + "/MHPC/settings/mhpc_config.info")
+        pd = builder.MHPCProblemData(builder.QuadReference(tree + "/Reference/Data/bound/quad_reference.csv"), cfg,
+                                     builder.load_cost_weights(tree + "/" + cfg["costFile"]), builder.load_constraint_params(tree + "/" + cfg["constraintParamFile"]))
+        pd.update()
+        phases, info = pd.describe(ubar_mode="gravity_comp")
+        assert info["shooting"] == [1, 1, 1, 0] and info["horizons"] == [4, 10, 10, 1]
+        x0 = np.vstack([info["x0"], info["x0"] + 0.01 * (x0[0] - pkg.problems.wb_nominal_state())])
     if which == "hkd":           # HKD-MPC trot: 24/24/0 phases, lift-off / touchdown reset maps, touchdown constraint from leg kinematics
         phases = pkg.problems.hkd_trot_problem(horizons=(3, 4, 3, 3))
         x0 = pkg.problems.hkd_ensemble_x0(2, 11, phases)
