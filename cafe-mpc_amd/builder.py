@@ -330,3 +330,67 @@ def shift_solver(solver_cls, lib, old_solver, old_phases, pd, slot_map, ubar_mod
         else:
             new.warm_start_phase(i, None, -1, 0)       # phase created by the update: zero trajectory (Trajectory constructor)
     return new, phases, info
+
+
+# --------------------------------------------------------------------------------------------- HKD-MPC problem
+def load_hkd_constraint_params(path):
+    p = load_info(path)
+    reb = lambda n: Reb(float(p[n + "_ReB"]["delta"]), float(p[n + "_ReB"]["delta_min"]), float(p[n + "_ReB"]["eps"]))
+    td = p["TD_AL"]
+    return dict(grf=reb("GRF"), swing=reb("Swing"), td=Al(float(td["sigma"]), float(td["lambda"]), float(td["sigma_max"])))
+
+
+def build_hkd_problem(ref, cpar, plan_duration=0.6, dt_sim=0.01, nsteps_between_mpc=2):
+    """HKDProblem::initialization (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:14-97) with the constants of HKDMPCSolver::initialize
+    (HKDMPC/HKDMPC.cpp:26-29).  `ref` must have been loaded with reorder=True (HKDMPC.h:32: legs FR FL HR HL, qJd zeroed).
+    Returns (phases, info)."""
+    plan = F32(plan_duration); dt = F32(dt_sim); dt_mpc = F32(dt * F32(nsteps_between_mpc))
+    ref.initialize(plan)
+    starts, ends, hors, contacts = [], [], [], []
+    t = F32(0); start = F32(0)
+    c_prev = ref.contact_at(t)
+    while _approx_leq(t, plan):                                                # HKDProblem.cpp:34-63
+        c_cur = ref.contact_at(t)
+        if (c_cur != c_prev).any() or (float(t) > float(plan) or _approx_eq(t, plan)):
+            end = t
+            starts.append(start); ends.append(end); hors.append(int(round(float(F32(end - start) / dt)))); contacts.append(c_prev.copy())
+            c_prev = c_cur; start = end
+        t = F32(t + dt)
+
+    def hkd_x(a):                                                              # HKDSinglePhaseReference::get_reference_at_t (HKDReference.cpp:23-61)
+        b = a["body_state"]
+        q = np.concatenate([a["foot_placements"][3 * l:3 * l + 3] if a["contact"][l] > 0 else a["jnt_angle"][3 * l:3 * l + 3] for l in range(4)])
+        return np.concatenate([b[3:6], b[0:3], b[9:12], b[6:9], q])
+
+    phases = []
+    n = len(starts)
+    for i in range(n):
+        h = hors[i]
+        nxt = contacts[i + 1] if i + 1 < n else ref.contact_at(F32(plan + dt_mpc))         # HKDProblem.cpp:283-291
+        t_off = float(F32(starts[i] - starts[0]))
+        xr = np.zeros((h + 1, 24)); ur = np.zeros((h + 1, 24)); fp = np.zeros((h + 1, 12)); bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32)
+        X0 = np.zeros((h + 1, 24))
+        for k in range(h + 1):
+            a = ref.at(F32(t_off + k * float(dt)))
+            xr[k] = hkd_x(a); ur[k] = np.concatenate([a["grf"], a["jnt_vel"]]); fp[k] = a["foot_placements"]; bp[k] = a["body_state"][:3]; rc[k] = a["contact"]
+            X0[k] = hkd_x(ref.at(F32(float(starts[i]) + k * float(dt))))
+        ph = problems.hkd_phase(h, float(dt), t_off, contacts[i], nxt, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
+        ph["desc"].reb_grf = cpar["grf"]; ph["desc"].al_td = cpar["td"]
+        ph["Xbar"] = X0; ph["Ubar"] = np.zeros((h, 24))
+        phases.append(ph)
+    info = dict(start_times=[float(s) for s in starts], end_times=[float(e) for e in ends], horizons=hors, contacts=[c.tolist() for c in contacts], x0=phases[0]["Xbar"][0].copy())
+    return phases, info
+
+
+def hkd_next_footholds(solver, contacts, problem=0):
+    """HKDMPCSolver::update_foot_placement (HKDMPC/HKDMPC.cpp:207-240): for every leg the qdummy entries at the start of the first
+    phase it lands in (pattern 0 -> 1 along the contact sequence, search stops after the fifth phase pair).  Returns {leg: pf(3) float32}."""
+    out = {}
+    n = len(contacts)
+    for i in range(n - 1):
+        for l in range(4):
+            if l not in out and contacts[i][l] == 0 and contacts[i + 1][l] == 1:
+                out[l] = solver.field(i + 1, "XBAR", b0=problem, nb=1)[0, 0, 12 + 3 * l:15 + 3 * l].astype(np.float32)
+        if i >= 4:
+            break
+    return out

@@ -28,4 +28,8 @@ for f in ("mhpc_config.info", "cost_weights_regular.JSON", "constraint_params_re
     os.makedirs(os.path.join(OUT, "MHPC/settings"), exist_ok=True)
     shutil.copy(os.path.join(REF, "MHPC/settings", f), os.path.join(OUT, "MHPC/settings", f))
     os.chmod(os.path.join(OUT, "MHPC/settings", f), 0o644)
+for f in ("constraint_params.info", "ddp_setting.info"):
+    os.makedirs(os.path.join(OUT, "HKDMPC/settings"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "HKDMPC/settings", f), os.path.join(OUT, "HKDMPC/settings", f))
+    os.chmod(os.path.join(OUT, "HKDMPC/settings", f), 0o644)
 print("wrote", OUT)

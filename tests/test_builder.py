@@ -61,3 +61,26 @@ def test_oracle_solves_shipped_gaits(oracle_lib, gait):
     ia = s.info_arrays()
     assert ia["status"][0] == 0 and ia["n_iters"][0] >= 2
     assert ia["dyn_feas"][0] < 0.2 * f0 and ia["max_tconstr"][0] < 5e-3
+
+
+def test_hkd_problem_from_shipped_bound_gait(oracle_lib):
+    """HKDProblem::initialization + HKDMPCSolver constants on the gait file HKDMPC.h:30 names, solved by the oracle; foot-placement
+    extraction (HKDMPC.cpp:207-240) returns the landing spots the reset map projected on the ground."""
+    ref = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"), reorder=True)
+    cpar = builder.load_hkd_constraint_params(os.path.join(TREE, "HKDMPC/settings/constraint_params.info"))
+    phases, info = builder.build_hkd_problem(ref, cpar)
+    assert sum(info["horizons"]) == 60 and info["contacts"][0] == [1, 1, 1, 1] and info["contacts"][1] == [1, 1, 0, 0]      # FR FL HR HL: front stance
+    d0 = phases[0]["desc"]
+    assert d0.model == pkg.MODEL_HKD and abs(d0.reb_grf.eps - 0.5) < 1e-15 and d0.al_td.sigma == 20.0 and abs(d0.mu - 0.7) < 1e-15
+    opt = builder.load_ddp_setting(os.path.join(TREE, "HKDMPC/settings/ddp_setting.info"))
+    s = pkg.Solver(oracle_lib, phases, batch=1)
+    for i, p in enumerate(phases):
+        s.set_nominal(i, p["Xbar"], p["Ubar"])
+    s.set_initial_condition(info["x0"][None])
+    s.hybrid_rollout(0.0, opt); s.compute_cost(opt); f0 = s.measure_dynamics_feasibility()[0]
+    s.solve(opt)
+    ia = s.info_arrays()
+    # cold start on a kinematic (not dynamically consistent) reference with 5 x 10 iterations: the defects close, the plan is not converged
+    assert ia["status"][0] == 0 and ia["n_iters"][0] == 50 and ia["dyn_feas"][0] < 0.2 * f0
+    pf = builder.hkd_next_footholds(s, info["contacts"])
+    assert set(pf) >= {2, 3} and all(abs(v[2]) < 1e-12 for v in pf.values())       # hind legs land first; cmap = (1,1,0) puts the foothold on z = 0

@@ -121,6 +121,24 @@ def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, gait):
     assert cmd["N_mpcsteps"] == 8 and np.isfinite(cmd["feedback"]).all()
 
 
+def test_full_solve_parity_hkd_shipped_gait(hip_lib, oracle_lib):
+    """HKD-MPC problem as HKDProblem::initialization builds it from the bound gait (HKDMPC.h:30) with HKDMPC/settings: 7 phases / 60 knots."""
+    import importlib, os
+    from conftest import ROOT
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    ref = builder.QuadReference(os.path.join(tree, "Reference/Data/bound/quad_reference.csv"), reorder=True)
+    phases, info = builder.build_hkd_problem(ref, builder.load_hkd_constraint_params(os.path.join(tree, "HKDMPC/settings/constraint_params.info")))
+    opt = builder.load_ddp_setting(os.path.join(tree, "HKDMPC/settings/ddp_setting.info"))
+    opt.max_AL_iter, opt.max_DDP_iter = 2, 4
+    x0 = np.vstack([info["x0"], info["x0"]]); x0[1, :12] += 0.01
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases), rtol=1e-5)
+    pf_o, pf_g = builder.hkd_next_footholds(so, info["contacts"]), builder.hkd_next_footholds(sg, info["contacts"])
+    assert set(pf_g) == set(pf_o) and all(np.allclose(pf_g[l], pf_o[l], atol=1e-6) for l in pf_g)
+
+
 def test_receding_horizon_loop_parity(hip_lib, oracle_lib):
     """The MPC loop of testTrajOptInLoop.cpp:85-117 in shape: solve, then per tick MHPCProblem::update (phase table shift incl. the
     young single-shooting phases), warm start moved device to device (hsddp_warm_start_phase), runtime iteration limits.  GPU and
