@@ -569,8 +569,14 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
+    // the barrier derivative tables only need g, delta, eps of the rollout: their global loads are issued together with x, u
     HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 12) { L.u[tid] = P.U[ku + tid]; L.fext[tid] = 0.0; }
-             if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; })
+             if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
+             for (int c = tid; c < P.ng; c += NT) {
+                 size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
+                 if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
+                 D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
+             })
     HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
     LQ_STAMP0()
     wb_terms<NT>(L, md, true);
@@ -627,11 +633,6 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
-    HS_PHASE_L(NT, for (int c = tid; c < P.ng; c += NT) {
-        size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
-        if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
-        D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
-    })
     HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
         double lxd = dt * P.q[d] * (L.x[d] - P.xr[(size_t)k * 36 + d]);
