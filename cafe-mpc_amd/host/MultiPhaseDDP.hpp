@@ -79,6 +79,17 @@ public:
         return out;
     }
     int last_error() const { return rc_; }
+    // publish_mpc_cmd (MHPC/MHPCLocomotion.cpp:190-287): the first n_steps control knots of one problem in MHPC_Command_lcmt field order,
+    // packed on the device (fp32); the caller copies the rows into its lcm-gen struct
+    std::vector<unsigned int> export_mpc_command(int problem, int n_steps, double mpc_time, double dt, const float* status_times = nullptr) {
+        std::vector<unsigned int> words(1 + (size_t)n_steps * HSDDP_CMD_WORDS_PER_STEP);
+        rc_ = hsddp_export_mpc_command(h_, problem, n_steps, mpc_time, dt, status_times, words.data());
+        return words;
+    }
+    // receding-horizon step (MHPCProblem::update): phase `dphase` continues phase `sphase` of the previous window (sphase < 0: new phase)
+    void warm_start_phase(int dphase, MultiPhaseDDP<T>* prev, int sphase, int popped_front) {
+        rc_ = hsddp_warm_start_phase(h_, dphase, prev ? prev->h_ : nullptr, sphase, popped_front);
+    }
     hsddp_handle_t* handle() { return h_; }
 
 private:
