@@ -686,7 +686,7 @@ int hsddp_get_kernel_times(hsddp_handle_t* h, int max_n, double* ms, long long* 
     if (pos < names_cap) names[pos] = 0;
     return n;
 }
-#ifdef LQ_PROF
+#if defined(LQ_PROF) || defined(ROLL_PROF)
 int hsddp_debug_lq_prof(unsigned long long* out16, int reset) {
     hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lq_prof), 16 * sizeof(unsigned long long));
     if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_lq_prof), z, sizeof(z)); }

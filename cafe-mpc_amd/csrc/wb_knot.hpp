@@ -55,8 +55,17 @@ struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (s
 };
 constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
-#if defined(LQ_PROF) && !defined(HS_HOST_EMU)
+#if defined(ROLL_PROF) && !defined(HS_HOST_EMU)
+#define RL_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
+#define RL_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
+#else
+#define RL_STAMP(i)
+#define RL_STAMP0()
+#endif
+#if (defined(LQ_PROF) || defined(ROLL_PROF)) && !defined(HS_HOST_EMU)
 __device__ unsigned long long g_lq_prof[16];
+#endif
+#if defined(LQ_PROF) && !defined(HS_HOST_EMU)
 #define LQ_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
 #define LQ_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
 #else
@@ -364,28 +373,6 @@ HD double wb_constraint(const PhaseDev& P, const WbCore& L, int c) {
     return fy + P.mu * fz;
 }
 
-// running cost without barrier terms (tracking + foot costs), evaluated by one lane.  MHPCCost.cpp:4-245
-HD double wb_running_cost_base(const PhaseDev& P, const WbCore& L, int k) {
-    const double dt = P.dt;
-    double lq = 0, lr = 0;
-    for (int i = 0; i < 36; i++) { double d = L.x[i] - P.xr[(size_t)k * 36 + i]; lq += d * P.q[i] * d; }
-    for (int i = 0; i < 12; i++) { double d = L.u[i] - P.ur[(size_t)k * 12 + i]; lr += d * P.r[i] * d; }
-    double l = 0.5 * lq; l += 0.5 * lr; l *= dt;
-    const int* rc = P.ref_contact + (size_t)k * 4; const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
-    double l2 = 0, l3 = 0, l4 = 0;
-    for (int f = 0; f < 4; f++) {
-        double d0 = (L.fpos[3 * f] - L.x[0]) - (fp[3 * f] - bp[0]), d1 = (L.fpos[3 * f + 1] - L.x[1]) - (fp[3 * f + 1] - bp[1]), d2 = (L.fpos[3 * f + 2] - L.x[2]) - (fp[3 * f + 2] - bp[2]);
-        if (rc[f] > 0 && P.w_foot_reg[0] >= 0) l2 += 0.5 * (d0 * P.w_foot_reg[0] * d0 + d1 * P.w_foot_reg[1] * d1 + d2 * P.w_foot_reg[2] * d2) * dt;
-        if (rc[f] == 0 && P.w_swing_pos[0] >= 0) l3 += 0.5 * (d0 * P.w_swing_pos[0] * d0 + d1 * P.w_swing_pos[1] * d1 + d2 * P.w_swing_pos[2] * d2) * dt;
-        if (rc[f] == 0 && P.w_swing_vel[0] >= 0) {
-            double v0 = L.fvel[3 * f] - P.foot_vel[(size_t)k * 12 + 3 * f], v1 = L.fvel[3 * f + 1] - P.foot_vel[(size_t)k * 12 + 3 * f + 1], v2 = L.fvel[3 * f + 2] - P.foot_vel[(size_t)k * 12 + 3 * f + 2];
-            l4 += 0.5 * (v0 * P.w_swing_vel[0] * v0 + v1 * P.w_swing_vel[1] * v1 + v2 * P.w_swing_vel[2] * v2) * dt;
-        }
-    }
-    l += l2; l += l3; l += l4;
-    return l;
-}
-
 struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // per (problem, slot) partials
 
 // -------------------------------------------------------------------------------------------------------
@@ -398,49 +385,96 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12;
     double* Kst = L.Jc();   // 432 doubles: [Jc | Xm] are free until the contact solve
+    RL_STAMP0()
+    // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five): the references and the
+    // barrier parameters wait in LDS (tmp / red / the tail of GG) until the phases that use them
+    const size_t kk = (size_t)b * h + k;
     HS_PHASE(NT, if (tid < 36) {
         double xb = P.Xbar[kx + tid], x = ss ? L.xnext[tid] : xb + eps * P.dX[kx + tid];
         L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
-    } if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
-      for (int i = tid; i < 432; i += NT) Kst[i] = P.K[((size_t)b * h + k) * 432 + i];)
+        L.tmp[tid] = P.xr[(size_t)k * 36 + tid];
+        L.red[tid] = ss ? 0.0 : P.Xbar[kx + 36 + tid] + eps * P.dX[kx + 36 + tid];
+    } else if (tid < 48) {
+        const int i = tid - 36;
+        L.tmp[tid] = P.ur[(size_t)k * 12 + i]; L.red[tid] = P.Ubar[ku + i] + eps * P.dU[ku + i];
+    } else if (tid < 60) L.tmp[tid] = P.foot_vel[(size_t)k * 12 + tid - 48];
+      if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
+      for (int c = tid; c < P.ng; c += NT) { L.gval()[c] = P.eps[kk * P.ng + c]; L.bar()[c] = P.delta[kk * P.ng + c]; }
+      for (int i = tid; i < 432; i += NT) Kst[i] = P.K[kk * 432 + i];)
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
-        double u = P.Ubar[ku + tid] + eps * P.dU[ku + tid] + s;
+        double u = L.red[36 + tid] + s;
         L.u[tid] = u; P.U[ku + tid] = u; L.tau[6 + tid] = u;
     })
+    RL_STAMP(0)
     wb_terms<NT>(L, md, true);
+    RL_STAMP(1)
     wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
-    // integrate, defect of knot k+1 (and of knot 0 for the very first knot of phase 0), outputs
+    RL_STAMP(2)
+    RL_STAMP(3)
+    // integrate, defect of knot k+1 (and of knot 0 for the very first knot of phase 0), constraint values + barrier, cost terms:
+    // one phase, every lane its own entries; the sums are taken afterwards in the reference's order by four lanes in parallel
+    double* S = L.JX;      // scratch (the contact solve is done): [0,36) x-terms | [36,48) u-terms | [48,60) foot terms | [64,100) defect^2 | [100,136) xsim^2
     HS_PHASE(NT, if (tid < 36) {
-        double xs = (tid < 18) ? L.x[tid] + L.x[18 + tid] * P.dt : L.x[tid] + L.qdd[tid - 18] * P.dt;
+        const double xs = (tid < 18) ? L.x[tid] + L.x[18 + tid] * P.dt : L.x[tid] + L.qdd[tid - 18] * P.dt;
         P.Xsim[kx + 36 + tid] = xs;
-        double xn = ss ? xs : P.Xbar[kx + 36 + tid] + eps * P.dX[kx + 36 + tid];
-        double d = xs - xn; P.Defect[kx + 36 + tid] = d;
+        const double xn = ss ? xs : L.red[tid];
+        const double d = xs - xn; P.Defect[kx + 36 + tid] = d;
         if (ss) { L.xnext[tid] = xs; if (k == 0) { P.Xsim[kx + tid] = L.x[tid]; P.Defect[kx + tid] = 0.0; } }
-        double dsq = d * d, nsq = xs * xs;
-        if (x0 != nullptr && k == 0) { double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
-        L.red[tid] = dsq; L.tmp[tid] = nsq;
-    } if (tid < 12) P.Y[((size_t)b * h + k) * 12 + tid] = L.grf[tid];)
-    // constraints + barrier
-    HS_PHASE(NT, for (int c = tid; c < P.ng; c += NT) {
-        double g = wb_constraint(P, L, c); L.gval()[c] = g;
-        size_t gi = ((size_t)b * h + k) * P.ng + c; P.g[gi] = g;
-        L.bar()[c] = P.eps[gi] * reb_barrier(g, P.delta[gi]);
-    })
-    HS_PHASE(NT, if (tid == 0) {
-        double lb = wb_running_cost_base(P, L, k);
-        P.lbase[(size_t)b * h + k] = lb;
-        double l = lb;
-        if (reb_active) {   // per constraint object: ReB_cost then l += dt*ReB_cost (SinglePhase.cpp:394-402)
-            int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz);
-            for (int gI = 0; gI < nobj; gI++) { double c = 0; for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i]; l += P.dt * c; }
+        double dsq = d * d;
+        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
+        S[64 + tid] = dsq; S[100 + tid] = xs * xs;
+        const double dx = L.x[tid] - L.tmp[tid]; S[tid] = dx * P.q[tid] * dx;
+    } else if (tid < 48) {
+        const int i = tid - 36; P.Y[kk * 12 + i] = L.grf[i];
+        const double du = L.u[i] - L.tmp[tid]; S[tid] = du * P.r[i] * du;
+    } else if (tid < 52) {     // foot costs of foot f: place regulariser (stance), swing position, swing velocity (MHPCCost.cpp:4-245)
+        const int f = tid - 48; const int rc = P.ref_contact[(size_t)k * 4 + f];
+        const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
+        const double d0 = (L.fpos[3 * f] - L.x[0]) - (fp[3 * f] - bp[0]), d1 = (L.fpos[3 * f + 1] - L.x[1]) - (fp[3 * f + 1] - bp[1]), d2 = (L.fpos[3 * f + 2] - L.x[2]) - (fp[3 * f + 2] - bp[2]);
+        double l2 = 0, l3 = 0, l4 = 0;
+        if (rc > 0 && P.w_foot_reg[0] >= 0) l2 = 0.5 * (d0 * P.w_foot_reg[0] * d0 + d1 * P.w_foot_reg[1] * d1 + d2 * P.w_foot_reg[2] * d2) * P.dt;
+        if (rc == 0 && P.w_swing_pos[0] >= 0) l3 = 0.5 * (d0 * P.w_swing_pos[0] * d0 + d1 * P.w_swing_pos[1] * d1 + d2 * P.w_swing_pos[2] * d2) * P.dt;
+        if (rc == 0 && P.w_swing_vel[0] >= 0) {
+            const double v0 = L.fvel[3 * f] - L.tmp[48 + 3 * f], v1 = L.fvel[3 * f + 1] - L.tmp[48 + 3 * f + 1], v2 = L.fvel[3 * f + 2] - L.tmp[48 + 3 * f + 2];
+            l4 = 0.5 * (v0 * P.w_swing_vel[0] * v0 + v1 * P.w_swing_vel[1] * v1 + v2 * P.w_swing_vel[2] * v2) * P.dt;
         }
-        P.l[(size_t)b * h + k] = l;
+        S[48 + f] = l2; S[52 + f] = l3; S[56 + f] = l4;
+    }
+    for (int c = tid; c < P.ng; c += NT) {
+        const double g = wb_constraint(P, L, c), e = L.gval()[c], dl = L.bar()[c];
+        P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl);
+    })
+    RL_STAMP(4)
+    HS_PHASE(NT, if (tid == 0) {          // running cost in the reference's order of additions
+        double lq = 0, lr = 0;
+        for (int i = 0; i < 36; i++) lq += S[i];
+        for (int i = 0; i < 12; i++) lr += S[36 + i];
+        double l = 0.5 * lq; l += 0.5 * lr; l *= P.dt;
+        double l2 = 0, l3 = 0, l4 = 0;
+        for (int f = 0; f < 4; f++) { l2 += S[48 + f]; l3 += S[52 + f]; l4 += S[56 + f]; }
+        l += l2; l += l3; l += l4;
+        P.lbase[kk] = l; S[140] = l;
+    } else if (tid >= 8 && tid < 13) {    // ReB_cost of constraint object tid-8 (SinglePhase.cpp:394-402)
+        int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); const int gI = tid - 8;
+        double c = 0; if (gI < nobj) for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i];
+        S[141 + gI] = c;
+    } else if (tid == 16) {
         double ming = 0; for (int c = 0; c < P.ng; c++) ming = fmin(ming, L.gval()[c]);
-        double dsq = 0, nsq = 0; for (int i = 0; i < 36; i++) { dsq += L.red[i]; nsq += L.tmp[i]; }
-        so.cost[slot] = l; so.dsq[slot] = dsq; so.ming[slot] = ming; so.maxh[slot] = 0.0;
+        so.ming[slot] = ming; so.maxh[slot] = 0.0;
+    } else if (tid == 32) {
+        double dsq = 0; for (int i = 0; i < 36; i++) dsq += S[64 + i];
+        so.dsq[slot] = dsq;
+    } else if (tid == 48) {
+        double nsq = 0; for (int i = 0; i < 36; i++) nsq += S[100 + i];
         if (sqrt(nsq) > 1e6 || !(nsq == nsq)) fail_flag[b] = 1;   // SinglePhase.cpp:205
     })
+    HS_PHASE(NT, if (tid == 0) {
+        double l = S[140];
+        if (reb_active) { int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); for (int gI = 0; gI < nobj; gI++) l += P.dt * S[141 + gI]; }
+        P.l[kk] = l; so.cost[slot] = l;
+    })
+    RL_STAMP(5)
 }
 
 // terminal cost without AL (tracking + foot-place reg (x1) + touchdown-velocity penalty). MHPCCost.cpp:67-87,255-268
@@ -504,13 +538,23 @@ HD void wb_rollout_terminal(WbCore& L, const PhaseDev& P, const PhaseDev* Pn, co
 // coalesced copy LDS -> global
 template <int NT> HD void store_block(double* dst, const double* src, int n) { HS_PHASE_L(NT, for (int i = tid; i < n; i += NT) dst[i] = src[i];) }
 
+// References of knot k for the cost partials, fetched with the state so that no later phase waits on HBM:
+//   tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
+HD void wb_cost_prefetch(WbCore& L, const PhaseDev& P, int k, int tid) {
+    if (tid < 36) L.tmp[tid] = P.xr[(size_t)k * 36 + tid];
+    else if (tid < 48) L.tmp[tid] = P.ur[(size_t)k * 12 + tid - 36];
+    if (tid < 12) { L.red[tid] = P.foot_pos[(size_t)k * 12 + tid]; L.red[12 + tid] = P.foot_vel[(size_t)k * 12 + tid]; }
+    else if (tid < 15) L.red[12 + tid] = P.body_pos[(size_t)k * 3 + tid - 12];
+    else if (tid < 19) L.red[13 + tid] = (double)P.ref_contact[(size_t)k * 4 + tid - 15];
+}
 // foot-cost Jacobian blocks of the knot: JP (position-type rows, base-translation and velocity columns zero),
 // JW (velocity-type rows [d vel/dq | J]), with per-row weights (dt folded in) and residuals.  `terminal` selects the
 // terminal cost objects (foot-place reg x2, touchdown velocity) instead of the running ones.
 template <int NT>
 HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
     WbCore& L = S.c; WbDeriv& D = S.d;
-    const int* rc = P.ref_contact + (size_t)k * 4; const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
+    const double* rc = L.red + 28; const double* fp = L.red; const double* bp = L.red + 24;     // wb_cost_prefetch
+    (void)k;
     HS_PHASE(NT,
         if (tid < 12) {
             const int f = tid / 3, a = tid % 3;
@@ -525,7 +569,7 @@ HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
             }
             D.wp[tid] = wpos; D.wv[tid] = wvel;
             D.ep[tid] = (L.fpos[tid] - L.x[a]) - (fp[tid] - bp[a]);
-            D.ev[tid] = terminal ? L.fvel[tid] : (L.fvel[tid] - P.foot_vel[(size_t)k * 12 + tid]);
+            D.ev[tid] = terminal ? L.fvel[tid] : (L.fvel[tid] - L.red[12 + tid]);
         })
 }
 // column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  written to out[0..35] (stride 36), and the gradient entry.  The blocks are
@@ -572,6 +616,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     // the barrier derivative tables only need g, delta, eps of the rollout: their global loads are issued together with x, u
     HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 12) { L.u[tid] = P.U[ku + tid]; L.fext[tid] = 0.0; }
              if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
+             wb_cost_prefetch(L, P, k, tid);
              for (int c = tid; c < P.ng; c += NT) {
                  size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
                  if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
@@ -635,7 +680,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     wb_cost_blocks<NT>(S, P, k, false);
     HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
-        double lxd = dt * P.q[d] * (L.x[d] - P.xr[(size_t)k * 36 + d]);
+        double lxd = dt * P.q[d] * (L.x[d] - L.tmp[d]);
         double diag = dt * P.q[d];
         lxd += wb_cost_column(D, L.Jall, L.dvel(), d, D.W + d);
         // ReB fold on x (joint limits: x[6+i], height: x[2]) — rank-1 updates on the diagonal (ConstraintsBase.h:282-287)
@@ -657,7 +702,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     HS_PHASE_L(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
     HS_PHASE_L(NT, if (tid < 12) {
         const int i = tid;
-        double lu = dt * P.r[i] * (L.u[i] - P.ur[(size_t)k * 12 + i]), luu = dt * P.r[i];
+        double lu = dt * P.r[i] * (L.u[i] - L.tmp[36 + i]), luu = dt * P.r[i];
         if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }
         P.lu[kk * P.rs + i] = lu; L.Jc()[i + 12 * i] = luu;
         // y: grf pyramid rows [0 0 1; -1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu] for foot f = i/3
@@ -685,14 +730,15 @@ HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const 
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 36;
-    HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;)
+    HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
+             wb_cost_prefetch(L, P, h, tid);)
     wb_terms<NT>(L, md, true);
     // d(J v)/dq with psi_kin at (q, v): kinematic lanes only
     wb_dpass<NT>(L, D, md, 0.0, 1.0, 1.0, 0.0, true);
     wb_cost_blocks<NT>(S, P, h, true);
     HS_PHASE(NT, if (tid < 36) {
         const int d = tid;
-        double px = P.qf[d] * (L.x[d] - P.xr[(size_t)h * 36 + d]);
+        double px = P.qf[d] * (L.x[d] - L.tmp[d]);
         px += wb_cost_column(D, L.Jall, L.dvel(), d, D.W + d);
         double diag = P.qf[d];
         if (al_active && P.nt > 0) {   // compute_AL_partials (ConstraintsBase.h:412-425); hx[0:18] = J_foot,z (psi_dyn)

@@ -29,7 +29,14 @@ if hasattr(lib, "hsddp_debug_sweep_prof"):
     tot = sum(buf)
     for i, n in enumerate(names[:9] if False else names):
         if i < 16: print(f"  stamp {i} {n:16s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
-if hasattr(lib, "hsddp_debug_lq_prof"):
+if hasattr(lib, "hsddp_debug_lq_prof") and os.environ.get("ROLL_PROF"):
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.hsddp_debug_lq_prof(buf, 1)
+    s.hybrid_rollout(1.0, opt)
+    lib.hsddp_debug_lq_prof(buf, 0)
+    for i, n in enumerate(["load x, K, u", "terms", "kkt_direct", "integrate/defect", "constraints", "cost (lane 0)"]):
+        print(f"  rollout stamp {i} {n:20s} {buf[i]:10d} cycles")
+elif hasattr(lib, "hsddp_debug_lq_prof"):
     buf = (ctypes.c_ulonglong * 16)()
     lib.hsddp_debug_lq_prof(buf, 1)
     s.LQ_approximation(opt)
