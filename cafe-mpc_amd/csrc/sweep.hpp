@@ -19,6 +19,7 @@
 //    sequential critical path.
 //  * the 12x12 Cholesky + inverse runs inside wave 0 with unrolled register recurrences (no workgroup barrier).
 #pragma once
+#include <cstddef>
 #include "hs_types.hpp"
 
 namespace hs {
@@ -436,55 +437,78 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
     _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(2 * RL::rA + 2 * RL::rB + r) = rec_[RL::oLuu + NT * r]; \
     PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
             : (tid < 2 * N + 2 * M) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
-#define SW_LIN_COMMIT() { \
-    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[e] = PRE(r); S.Qxx[e] = PRE(RL::rA + r); } } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) { S.B[e] = PRE(2 * RL::rA + r); S.K[e] = PRE(2 * RL::rA + RL::rB + r); } } \
-    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) S.Quu[e] = PRE(2 * RL::rA + 2 * RL::rB + r); } \
+#define SW_LIN_COMMIT(p_) { \
+    double* A_ = (p_) ? S.H : S.A; double* Q_ = (p_) ? S.HA : S.Qxx; double* B_ = (p_) ? S.HB : S.B; double* K_ = (p_) ? S.Qux : S.K; double* U_ = (p_) ? S.LQ : S.Quu; \
+    double* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { A_[e] = PRE(r); Q_[e] = PRE(RL::rA + r); } } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) { B_[e] = PRE(2 * RL::rA + r); K_[e] = PRE(2 * RL::rA + RL::rB + r); } } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) U_[e] = PRE(2 * RL::rA + 2 * RL::rB + r); } \
     { const double v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
-      if (tid < N) S.Qx[tid] = v_; else if (tid < N + M) S.Qu[tid - N] = v_; else if (tid < N + 2 * M) S.dU[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) S.def[tid - N - 2 * M] = v_; } }
+      if (tid < N) ((p_) ? S.red : S.Qx)[tid] = v_; else if (tid < N + M) ((p_) ? S.red + 64 : S.Qu)[tid - N] = v_; \
+      else if (tid < N + 2 * M) ((p_) ? S.red + 128 : S.dU)[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) ((p_) ? S.red + 192 : S.def)[tid - N - 2 * M] = v_; } }
 
-// one phase of the linear rollout; on entry S.c.xfer holds dx_init (Px * dX_end of the previous phase, or 0), on exit dX_end
+// one phase of the linear rollout; on entry S.c.xfer holds dx_init (Px * dX_end of the previous phase, or 0), on exit dX_end.
+// Two LDS sets (A, lxx, B, K, luu and the vectors) alternate between knots, so a knot costs two barriers: du = eps dU + K dx, then
+// dx+ = A dx + B du + eps defect together with the commit of the next knot's record into the other set.  The contributions to
+// dV_1 / dV_2 stay in registers (one partial sum per lane) and are added up once per phase.
 template <int NT, int N, int M, int PY>
 HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
-    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 128 + M <= NT - 64, "prefetch registers / lane maps");
+    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && N <= 64 && M <= 64, "prefetch registers / lane maps");
+    static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(double), "the partial-sum scratch must not reach dx");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
     SW_PRE_DECL
+#ifdef HS_HOST_EMU
+    static double acc1_all_[NT], acc2_all_[NT];
+    for (int t = 0; t < NT; t++) { acc1_all_[t] = 0.0; acc2_all_[t] = 0.0; }
+#define ACC1 acc1_all_[tid]
+#define ACC2 acc2_all_[tid]
+#else
+    double acc1_ = 0.0, acc2_ = 0.0;
+#define ACC1 acc1_
+#define ACC2 acc2_
+#endif
     // dX[0] = dx_init + eps * Defect[0]
     HS_PHASE(NT, if (tid < N) { double v = SWC.xfer[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
              SW_LIN_FETCH((size_t)b * h, 0))
+    HS_PHASE_L(NT, SW_LIN_COMMIT(0) if (1 < h) SW_LIN_FETCH((size_t)b * h + 1, 1))
     for (int k = 0; k < h; k++) {
         const size_t kk = (size_t)b * h + k;
-        HS_PHASE_L(NT, SW_LIN_COMMIT() if (k + 1 < h) SW_LIN_FETCH(kk + 1, k + 1))
-        HS_PHASE_L(NT, if (tid < M) { double s = eps * S.dU[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.K, tid, j, M) * S.dx[j]; S.du[tid] = s; })
+        const int p = k & 1;
+        const double* A_ = p ? S.H : S.A; const double* Q_ = p ? S.HA : S.Qxx; const double* B_ = p ? S.HB : S.B; const double* K_ = p ? S.Qux : S.K; const double* U_ = p ? S.LQ : S.Quu;
+        const double* Qx_ = p ? S.red : S.Qx; const double* Qu_ = p ? S.red + 64 : S.Qu; const double* dU_ = p ? S.red + 128 : S.dU; const double* def_ = p ? S.red + 192 : S.def;
+        const double* dxc = p ? S.dxn : S.dx; double* dxw = p ? S.dx : S.dxn;
+        HS_PHASE_L(NT, if (tid < M) { double s = eps * dU_[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(K_, tid, j, M) * dxc[j]; S.du[tid] = s; })
         HS_PHASE_L(NT,
             if (tid < N) {
                 double s = 0, q = 0;
-                _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(S.A, tid, j, N) * S.dx[j]; q += CM(S.Qxx, tid, j, N) * S.dx[j]; }
+                _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(A_, tid, j, N) * dxc[j]; q += CM(Q_, tid, j, N) * dxc[j]; }
                 double s2 = 0;
-                _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(S.B, tid, j, N) * S.du[j];
-                const double v = s + s2 + eps * S.def[tid];
-                S.dxn[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
-                S.red[tid] = S.dx[tid] * q;            // dx^T lxx dx contributions
-                S.red[64 + tid] = S.Qx[tid] * S.dx[tid];
+                _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(B_, tid, j, N) * S.du[j];
+                const double v = s + s2 + eps * def_[tid];
+                dxw[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
+                ACC2 += dxc[tid] * q;             // dx^T lxx dx
+                ACC1 += Qx_[tid] * dxc[tid];
             } else if (tid >= 128 && tid < 128 + M) {
                 const int a = tid - 128; double q = 0;
-                _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(S.Quu, a, j, M) * S.du[j];
-                S.red[tid] = S.du[a] * q; S.red[64 + tid] = S.Qu[a] * S.du[a];
-            })
-        HS_PHASE_L(NT, if (tid == 0) {
-            double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
-            for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; }
-            for (int j = 0; j < M; j++) { b1 += S.red[64 + 128 + j]; b2 += S.red[128 + j]; }
-            SWC.dV1 += a1 + b1; SWC.dV2 += a2; SWC.dV2 += b2;      // (+ du^T lux dx with lux == 0)
-        } if (tid >= 64 && tid < 64 + N) S.dx[tid - 64] = S.dxn[tid - 64];)
+                _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(U_, a, j, M) * S.du[j];
+                ACC2 += S.du[a] * q; ACC1 += Qu_[a] * S.du[a];      // (+ du^T lux dx with lux == 0)
+            }
+            if (k + 1 < h) { SW_LIN_COMMIT(1 - p) if (k + 2 < h) SW_LIN_FETCH(kk + 2, k + 2) })
     }
-    // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx
+    const double* dxe = (h & 1) ? S.dxn : S.dx;
+    // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx ; then the per-lane partial sums of the whole phase
     HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
-    HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * S.dx[j]; S.red[tid] = S.dx[tid] * q; S.red[64 + tid] = P.Phix[(size_t)b * N + tid] * S.dx[tid]; })
-    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += S.red[64 + j]; a2 += S.red[j]; } SWC.dV1 += a1; SWC.dV2 += a2; }
-             if (tid >= 64 && tid < 64 + N) SWC.xfer[tid - 64] = S.dx[tid - 64];)
+    HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * dxe[j]; ACC2 += dxe[tid] * q; ACC1 += P.Phix[(size_t)b * N + tid] * dxe[tid]; })
+    double* scr = SS.raw;     // 2 x NT partial sums (the matrices are no longer needed; dx / dxn live beyond the first 2 NT doubles of every view)
+    HS_PHASE(NT, scr[tid] = ACC1; scr[NT + tid] = ACC2;)
+    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[j]; a2 += scr[NT + j]; }
+                                 double b1 = 0, b2 = 0; for (int j = 0; j < M; j++) { b1 += scr[128 + j]; b2 += scr[NT + 128 + j]; }
+                                 SWC.dV1 += a1 + b1; SWC.dV2 += a2; SWC.dV2 += b2; }
+             if (tid >= 64 && tid < 64 + N) SWC.xfer[tid - 64] = dxe[tid - 64];)
+#undef ACC1
+#undef ACC2
 }
 
 // linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
