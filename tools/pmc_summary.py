@@ -48,6 +48,8 @@ for k in sorted(set(fetch) | set(write)):
                          "fetch_bytes_per_knot_x2": 2 * fl / knots_512, "write_bytes_per_knot": wl / knots_512}
     traffic[k] = {"hbm_bytes_per_launch_batch4096_raw": 8 * (fl + wl), "hbm_bytes_per_launch_batch4096_fetch_x2": 8 * (2 * fl + wl),
                   "source": f"profiles/{tag}_pmc_batch512.json scaled x8 (traffic is linear in the batch)"}
+if not res["kernels"]:
+    sys.exit(f"no PMC data under {out}: nothing written")
 json.dump(res, open(f"profiles/{tag}_pmc_batch512.json", "w"), indent=1)
 json.dump(traffic, open("profiles/r01_traffic.json", "w"), indent=1)
 print("wrote profiles/%s_*" % tag, list(res["kernels"]))
