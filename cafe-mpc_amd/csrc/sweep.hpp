@@ -77,33 +77,6 @@ __device__ unsigned long long g_sw_prof[16];
 #define PRE(r) pre_[r]
 #endif
 
-// One TI x TJ register tile of  C(i,j) (+)= alpha * sum_t opA(i,t) * B(t,j) ;  opA(i,t) = TA ? A[t + lda*i] : A[i + lda*t]
-template <bool TA, int TI, int TJ, int K>
-HD void mm_tile(int tile, int nti, double* C, int ldc, const double* A, int lda, const double* B, int ldb, bool acc, double alpha) {
-    const int ti = tile % nti, tj = tile / nti, i0 = TI * ti, j0 = TJ * tj;
-    double c[TI][TJ];
-    _Pragma("unroll")
-    for (int ii = 0; ii < TI; ii++) { _Pragma("unroll") for (int jj = 0; jj < TJ; jj++) c[ii][jj] = 0.0; }
-    HS_UNROLL_N(SW_UNROLL_N)    // loads in flight per tile vs registers (full unrolling needs ~450 registers -> 1 block per CU)
-    for (int t = 0; t < K; t++) {
-        double a[TI], bb[TJ];
-        _Pragma("unroll")
-        for (int ii = 0; ii < TI; ii++) a[ii] = TA ? A[t + lda * (i0 + ii)] : A[i0 + ii + lda * t];
-        _Pragma("unroll")
-        for (int jj = 0; jj < TJ; jj++) bb[jj] = B[t + ldb * (j0 + jj)];
-        _Pragma("unroll")
-        for (int ii = 0; ii < TI; ii++) { _Pragma("unroll") for (int jj = 0; jj < TJ; jj++) c[ii][jj] += a[ii] * bb[jj]; }
-    }
-    _Pragma("unroll")
-    for (int jj = 0; jj < TJ; jj++) {
-        _Pragma("unroll")
-        for (int ii = 0; ii < TI; ii++) {
-            double* p = C + (i0 + ii) + ldc * (j0 + jj);
-            *p = acc ? (*p + alpha * c[ii][jj]) : alpha * c[ii][jj];
-        }
-    }
-}
-
 // One 16x16 output tile per WAVE on the fp64 matrix cores:  Cout(i,j) = (Cin ? Cin(i,j) : 0) + sum_t opA(i,t) * B(t,j)
 // (v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns C rows (l>>4) + 4r, column l&15).
 // Each MFMA performs 1024 FMAs from 2 LDS reads per lane (1 B/FMA); the 3x3 VALU register tile needs 5.3 B/FMA and was
@@ -154,29 +127,6 @@ HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok
         })
     }
 }
-template <int N, int LD>
-HD void inv_col_w(const double* Lo, const double* rd, double* Inv, int c) {   // Inv[i*LD + c], symmetric
-    double y[N];
-    _Pragma("unroll")
-    for (int i = 0; i < N; i++) {
-        double s = (i == c) ? 1.0 : 0.0;
-        _Pragma("unroll")
-        for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * y[k];
-        y[i] = s * rd[i];
-        HS_CBAR();
-    }
-    _Pragma("unroll")
-    for (int i = N - 1; i >= 0; i--) {
-        double s = y[i];
-        _Pragma("unroll")
-        for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * y[k];
-        y[i] = s * rd[i];
-        HS_CBAR();
-    }
-    _Pragma("unroll")
-    for (int i = 0; i < N; i++) Inv[i * LD + c] = y[i];
-}
-
 // global (dense, ld = rows) <-> LDS (padded ld); threads stride over columns with a fixed row
 template <int NT> HD void ld_mat(int tid, double* dst, int ldd, const double* src, int rows, int cols) {
     const int i = tid % rows, j0 = tid / rows, js = NT / rows;

@@ -40,13 +40,11 @@ struct WbCore {
     unsigned long long tstamp;
 };
 struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (see accessors)
-    double JPW[2 * 432];               // column solve: staging of C (432) | B rows 18..35 (216) | D (144) ; then the foot-cost Jacobian blocks JP | JW (2 x 12 x 36)
+    double JPW[792];                   // column solve: staging of C (432) | B rows 18..35 (216) | D (144)
     double W[18 * 54 + 18 * 36];       // T[18][54] tangent columns + R[18][36] result rows ; finally a dense 36x36 staging tile for lxx / Phixx
     double wp[12], wv[12], ep[12], ev[12];
     double LGs[144], rdGs[12];         // Schur factor of the contact solve, kept while GG holds the foot tangents
     double bdt[2 * MAXG];              // barrier derivative tables
-    HD double* JP() { return JPW; }
-    HD double* JW() { return JPW + 432; }
     HD double* stC() { return JPW; }
     HD double* stB() { return JPW + 432; }
     HD double* stD() { return JPW + 648; }
@@ -125,16 +123,6 @@ template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, doubl
         if (i % HS_SOLVE_CBAR == 0) HS_CBAR();
     }
 }
-// column c of (L L^T)^-1 into Inv[:, c] (row-major ldi). Called by lane c.
-template <int N, int LD> HD void inv_col_s(const double* Lo, const double* rd, double* Inv, int ldi, int c) {
-    double y[N];
-    _Pragma("unroll")
-    for (int i = 0; i < N; i++) y[i] = (i == c) ? 1.0 : 0.0;
-    fwd_s<N, LD>(Lo, rd, y); bwd_s<N, LD>(Lo, rd, y);
-    _Pragma("unroll")
-    for (int i = 0; i < N; i++) Inv[i * ldi + c] = y[i];
-}
-
 
 HD LaneCfg lane_cfg(const ModelDev& md, bool kin, double mscale, double grav, double fscale, double vscale, double ascale, int aunit, int tq, int tv) {
     LaneCfg c;
