@@ -234,6 +234,43 @@ def test_batch_independence_and_full_size_properties(hip_lib):
     assert (info["dyn_feas"] < 0.5).all()       # started at ~6: multiple-shooting defects are being closed
 
 
+@pytest.mark.parametrize("which", ["barrel_roll_8_phases", "hkd"])
+def test_large_ensembles_of_the_other_baseline_configs(hip_lib, oracle_lib, which):
+    """BASELINE configs 3 and 4 in shape at a four-digit batch: the running barrel roll (8 hybrid phases) and the HKD-MPC problem.
+    Size-independent properties: duplicated initial states give bit-identical results wherever they sit in the batch, every problem
+    terminates with status 0, and a few sampled problems agree with the oracle solved one at a time."""
+    B = 1024
+    if which == "hkd":
+        phases = pkg.problems.hkd_trot_problem(horizons=(10, 10, 10, 10))
+        x0 = pkg.problems.hkd_ensemble_x0(B, 17, phases); opt = pkg.problems.hkd_ddp_setting(max_AL_iter=2, max_DDP_iter=3)
+    else:
+        phases, xinit = pkg.problems.barrel_roll_problem(repeat=2)
+        assert len(phases) == 8
+        g = pkg.problems.SplitMix64(5)
+        x0 = np.tile(xinit, (B, 1)); x0[:, 6:18] += 0.04 * (np.array([g.next() for _ in range(B * 12)]).reshape(B, 12) - 0.5)
+        opt = pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=2)
+    x0[B - 1] = x0[0]; x0[B // 2] = x0[1]
+    s = pkg.Solver(hip_lib, phases, batch=B)
+    for i, p in enumerate(phases):
+        s.set_nominal(i, p["Xbar"], p["Ubar"])
+    s.set_initial_condition(x0); s.solve(opt)
+    ia = s.info_arrays()
+    assert (ia["status"] == 0).all() and np.isfinite(ia["actual_cost"]).all()
+    for f in ("XBAR", "UBAR", "K"):
+        for i in (0, len(phases) - 1):
+            a = s.field(i, f)
+            assert np.array_equal(a[0], a[B - 1]) and np.array_equal(a[1], a[B // 2])
+    idx = [0, 7, B // 3]
+    so = pkg.Solver(oracle_lib, phases, batch=len(idx))
+    for i, p in enumerate(phases):
+        so.set_nominal(i, p["Xbar"], p["Ubar"])
+    so.set_initial_condition(np.ascontiguousarray(x0[idx])); so.solve(opt)
+    io = so.info_arrays()
+    for k in ("n_iters", "n_ls_iters", "status"):
+        assert np.array_equal(io[k], ia[k][idx]), k
+    assert np.allclose(io["actual_cost"], ia["actual_cost"][idx], rtol=1e-5)
+
+
 def test_flight_phase_and_four_foot_touchdown(hip_lib, oracle_lib):
     """Barrel-roll-like schedule (BarrelRollTO.cpp:70-81 shape): stance -> flight (no contact: free-fall dynamics,
     no GRF constraints) -> stance, i.e. a four-foot touchdown (12-row impulse, the mis-sliced impulse of quirk v)."""
