@@ -21,6 +21,7 @@
 #pragma once
 #include <cstddef>
 #include "hs_types.hpp"
+#include "hs_mfma.hpp"
 
 namespace hs {
 
@@ -81,7 +82,6 @@ __device__ unsigned long long g_sw_prof[16];
 // (v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns C rows (l>>4) + 4r, column l&15).
 // Each MFMA performs 1024 FMAs from 2 LDS reads per lane (1 B/FMA); the 3x3 VALU register tile needs 5.3 B/FMA and was
 // LDS-bandwidth bound.  Rows/cols beyond M_/N_ (36 = 2.25 tiles) are fed zeros / not stored.
-typedef double d4_t __attribute__((ext_vector_type(4)));
 template <bool TA, int K>
 HD void mfma_tile(int lane, double* Cout, int ldc, const double* Cin, int ldcin, int i0, int j0, int M_, int N_,
                   const double* A, int lda, const double* B, int ldb) {
@@ -153,57 +153,6 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     _Pragma("unroll") for (int r = 0; r < RL::rLyy; r++) { const int e = tid + NT * r; if (e < PY * PY) S.lyy[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + RL::rC + RL::rD + RL::rLuu + r); } \
     if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
     else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
-
-// Several 16x16 output tiles of ONE wave, accumulated together: the k-loop is outermost so that the MFMAs issued back to
-// back belong to different accumulators (a tile's own MFMAs form a dependent chain) and all operand loads of a k-step are in
-// flight together.  A tile may chain a second product onto the same accumulator (A^T HA + C^T lC).
-struct MTile {
-    double* Cout; int ldc; const double* Cin; int ldcin; int i0, j0, M_, N_;
-    const double* A; int lda; const double* B; int ldb; int K; bool TA;
-    const double* A2; int lda2; const double* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
-};
-template <int NTL, int KMAX, int KMAX2>
-HD void mfma_tiles(int lane, const MTile* td) {
-#ifdef HS_HOST_EMU
-    if (lane != 0) return;     // the emulator lets lane 0 stand for the wave (plain loops); the lane mapping is verified on the GPU
-    for (int t = 0; t < NTL; t++) {
-        const MTile& T = td[t];
-        for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
-            double s = T.Cin ? T.Cin[i + T.ldcin * j] : 0.0;
-            for (int k = 0; k < T.K; k++) s += (T.TA ? T.A[k + T.lda * i] : T.A[i + T.lda * k]) * T.B[k + T.ldb * j];
-            for (int k = 0; k < T.K2; k++) s += T.A2[k + T.lda2 * i] * T.B2[k + T.ldb2 * j];
-            T.Cout[i + T.ldc * j] = s;
-        }
-    }
-#else
-    const int li = lane & 15, lk = lane >> 4;
-    d4_t c[NTL];
-    _Pragma("unroll") for (int t = 0; t < NTL; t++) {
-        const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? td[t].Cin[row + td[t].ldcin * j] : 0.0; }
-    }
-    _Pragma("unroll") for (int kg = 0; kg < KMAX / 4; kg++) {
-        _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K) {
-            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
-            const double a = (i < td[t].M_) ? (td[t].TA ? td[t].A[k + td[t].lda * i] : td[t].A[i + td[t].lda * k]) : 0.0;
-            const double b = (j < td[t].N_) ? td[t].B[k + td[t].ldb * j] : 0.0;
-            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
-        }
-    }
-    _Pragma("unroll") for (int kg = 0; kg < KMAX2 / 4; kg++) {
-        _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K2) {
-            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
-            const double a = (i < td[t].M_) ? td[t].A2[k + td[t].lda2 * i] : 0.0;
-            const double b = (j < td[t].N_) ? td[t].B2[k + td[t].ldb2 * j] : 0.0;
-            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
-        }
-    }
-    _Pragma("unroll") for (int t = 0; t < NTL; t++) {
-        const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; if (row < td[t].M_ && j < td[t].N_) td[t].Cout[row + td[t].ldc * j] = c[t][r]; }
-    }
-#endif
-}
 
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
