@@ -1,0 +1,39 @@
+// Test harness: drives cafe-mpc_amd/host/mhpc_builder.hpp over a CAFE-MPC tree (tests/golden/cafe_tree) for a number of MPC ticks
+// and prints the phase table plus a byte hash of every descriptor array as JSON; tests/test_builder.py compares it with the Python
+// mirror (cafe_mpc_amd.builder) — both must produce identical descriptors.
+#include <cstdint>
+#include <iostream>
+#include "mhpc_builder.hpp"
+
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; } return h;
+}
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    const std::string root = argv[1], gait = argv[2]; const int nticks = std::atoi(argv[3]);
+    auto cfg = hsddp::load_mhpc_config(root + "/MHPC/settings/mhpc_config.info");
+    auto costs = hsddp::load_cost_weights(root + "/" + cfg.costFile);
+    auto cpar = hsddp::load_constraint_params(root + "/" + cfg.constraintParamFile);
+    hsddp::QuadReference ref; if (!ref.load(root + "/Reference/Data/" + gait + "/quad_reference.csv", false)) return 3;
+    hsddp::MhpcProblemData pd(ref, cfg, costs, cpar);
+    std::cout << "[";
+    for (int tick = 0; tick <= nticks; tick++) {
+        if (tick > 0) { pd.update(); std::cout << ","; }
+        std::vector<hsddp::PhaseBuffers> bufs; auto descs = pd.describe(bufs);
+        std::cout << "[";
+        for (size_t i = 0; i < descs.size(); i++) {
+            const auto& d = descs[i]; const auto& B = bufs[i];
+            uint64_t h = fnv(B.xr.data(), B.xr.size() * 8); h = fnv(B.ur.data(), B.ur.size() * 8, h); h = fnv(B.yr.data(), B.yr.size() * 8, h);
+            h = fnv(B.foot_pos.data(), B.foot_pos.size() * 8, h); h = fnv(B.foot_vel.data(), B.foot_vel.size() * 8, h); h = fnv(B.body_pos.data(), B.body_pos.size() * 8, h);
+            h = fnv(B.ref_contact.data(), B.ref_contact.size() * 4, h); h = fnv(B.Xbar.data(), B.Xbar.size() * 8, h);
+            uint64_t w = fnv(d.q, sizeof(d.q)); w = fnv(d.r, sizeof(d.r), w); w = fnv(d.qf, sizeof(d.qf), w); w = fnv(&d.reb_torque, sizeof(hsddp_reb_t) * 4, w); w = fnv(&d.al_td, sizeof(d.al_td), w);
+            std::cout << (i ? "," : "") << "{\"model\":" << d.model << ",\"h\":" << d.horizon << ",\"dt\":" << d.dt << ",\"t_offset\":" << d.t_offset
+                      << ",\"contact\":[" << d.contact[0] << "," << d.contact[1] << "," << d.contact[2] << "," << d.contact[3] << "],\"next_contact\":[" << d.next_contact[0] << ","
+                      << d.next_contact[1] << "," << d.next_contact[2] << "," << d.next_contact[3] << "],\"next_model\":" << d.next_model << ",\"shooting\":" << d.shooting
+                      << ",\"c_touchdown\":" << d.c_touchdown << ",\"w_td_vel\":" << d.w_td_vel << ",\"hash\":\"" << h << "\",\"whash\":\"" << w << "\"}";
+        }
+        std::cout << "]";
+    }
+    std::cout << "]\n";
+    return 0;
+}

@@ -84,3 +84,41 @@ def test_hkd_problem_from_shipped_bound_gait(oracle_lib):
     assert ia["status"][0] == 0 and ia["n_iters"][0] == 50 and ia["dyn_feas"][0] < 0.2 * f0
     pf = builder.hkd_next_footholds(s, info["contacts"])
     assert set(pf) >= {2, 3} and all(abs(v[2]) < 1e-12 for v in pf.values())       # hind legs land first; cmap = (1,1,0) puts the foothold on z = 0
+
+
+def _fnv(chunks):
+    h = 1469598103934665603
+    for c in chunks:
+        for byte in c:
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("gait", ["bound", "trot/dynfeas"])
+def test_cpp_builder_matches_python_mirror(tmp_path, gait):
+    """cafe-mpc_amd/host/mhpc_builder.hpp (what a CAFE-MPC maintainer links) and cafe_mpc_amd.builder produce identical descriptors —
+    phase table, flags, every reference array and weight, bit for bit — at initialisation and over 12 receding-horizon updates."""
+    import json, subprocess
+    exe = tmp_path / "builder_dump"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "builder_dump.cpp"), "-o", str(exe)])
+    nticks = 12
+    cpp = json.loads(subprocess.check_output([str(exe), TREE, gait, str(nticks)]))
+    cfg = builder.load_mhpc_config(TREE + "/MHPC/settings/mhpc_config.info")
+    pd = builder.MHPCProblemData(builder.QuadReference(os.path.join(TREE, "Reference/Data", gait, "quad_reference.csv")), cfg,
+                                 builder.load_cost_weights(TREE + "/" + cfg["costFile"]), builder.load_constraint_params(TREE + "/" + cfg["constraintParamFile"]))
+    for tick in range(nticks + 1):
+        if tick:
+            pd.update()
+        phases, _ = pd.describe()
+        assert len(phases) == len(cpp[tick])
+        for p, c in zip(phases, cpp[tick]):
+            d, B = p["desc"], p["bufs"]
+            assert (d.model, d.horizon, d.shooting, d.c_touchdown, d.next_model) == (c["model"], c["h"], c["shooting"], c["c_touchdown"], c["next_model"])
+            assert list(d.contact) == c["contact"] and list(d.next_contact) == c["next_contact"] and d.w_td_vel == c["w_td_vel"]
+            assert abs(d.t_offset - c["t_offset"]) < 1e-6 and abs(d.dt - c["dt"]) < 1e-12
+            arrays = [B["xr"], B["ur"]] + ([B["yr"]] if "yr" in B else [np.zeros(0)]) + [B["foot_pos"], B["foot_vel"], B["body_pos"], B["ref_contact"], p["Xbar"]]
+            assert str(_fnv(np.ascontiguousarray(a).tobytes() for a in arrays)) == c["hash"], (tick, d.model, d.horizon)
+            import ctypes
+            wb = [bytes(d.q), bytes(d.r), bytes(d.qf), ctypes.string_at(ctypes.addressof(d.reb_torque), 4 * ctypes.sizeof(d.reb_torque)), bytes(d.al_td)]
+            assert str(_fnv(wb)) == c["whash"]
