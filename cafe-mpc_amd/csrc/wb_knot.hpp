@@ -101,26 +101,32 @@ HD void chol_f(const double* A, double* Lo, double* rd, double diag_add) {
 #ifndef HS_SOLVE_CBAR
 #define HS_SOLVE_CBAR 100    // rows of a triangular solve between two scheduling fences (100: none; 1 keeps every row's loads behind the previous row)
 #endif
-// x = L^-1 b (forward) in registers; b/x are private arrays
+// x = L^-1 b (forward) in registers; b/x are private arrays.  The factor row of step i+1 is fetched from LDS (a broadcast read per
+// entry) into registers BEFORE the dependent multiply-add chain of row i runs: a single wave has no other wave to hide the LDS
+// latency behind, so the loads are batched and pipelined by hand (the fence keeps the compiler from sinking them back).
 template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, double* x) {
+    double lr[2][N];
     _Pragma("unroll")
     for (int i = 0; i < N; i++) {
+        if (i + 1 < N) { _Pragma("unroll") for (int k = 0; k <= i; k++) lr[(i + 1) & 1][k] = Lo[(i + 1) * LD + k]; }
+        HS_CBAR();
         double s = x[i];
         _Pragma("unroll")
-        for (int k = 0; k < i; k++) s -= Lo[i * LD + k] * x[k];
+        for (int k = 0; k < i; k++) s -= lr[i & 1][k] * x[k];
         x[i] = s * rd[i];
-        if (i % HS_SOLVE_CBAR == HS_SOLVE_CBAR - 1) HS_CBAR();
     }
 }
 // x = L^-T b (backward) in registers
 template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, double* x) {
+    double lr[2][N];
     _Pragma("unroll")
     for (int i = N - 1; i >= 0; i--) {
+        if (i > 0) { _Pragma("unroll") for (int k = i; k < N; k++) lr[(i - 1) & 1][k] = Lo[k * LD + (i - 1)]; }
+        HS_CBAR();
         double s = x[i];
         _Pragma("unroll")
-        for (int k = i + 1; k < N; k++) s -= Lo[k * LD + i] * x[k];
+        for (int k = i + 1; k < N; k++) s -= lr[i & 1][k] * x[k];
         x[i] = s * rd[i];
-        if (i % HS_SOLVE_CBAR == 0) HS_CBAR();
     }
 }
 
