@@ -78,6 +78,7 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     al(&P.l, B * hh); al(&P.lbase, B * hh);
     al(&P.Phi, B); al(&P.Phibase, B); al(&P.Phix, B * n); al(&P.Phixx, B * n * n); al(&P.H0, B * n * n); al(&P.Px, B * (size_t)P.next_n * n);
     al(&P.g, B * hh * ng); al(&P.delta, B * hh * ng); al(&P.eps, B * hh * ng);
+    if (wb) al(&P.kc, B * hh * KC_SIZE);
     al(&P.th, B * P.nt); al(&P.sigma, B * P.nt); al(&P.lambda, B * P.nt);
     if (!ok) return HSDDP_ENOMEM;
     // initial ReB / AL parameters (initialize_params, ConstraintsBase.h:173-180, 362-366)

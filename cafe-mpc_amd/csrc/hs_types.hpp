@@ -18,6 +18,11 @@ template <int N, int M, int PY> struct RecLayout {
     static constexpr int rounds = 2 * rA + rB + rC + rD + rLuu + rLyy;   // + 1 round for the vectors
 };
 
+// Contact-solve cache (whole-body knots): what the LAST rollout of a knot computed at (X[k], U[k]) and the LQ approximation would
+// recompute bit for bit at the same point (the reference does recompute it, WBM.cpp:463): the factor of M, X = L^-1 Jc^T, the Schur
+// factor, their reciprocal diagonals, qdd, the contact forces, all foot Jacobians, foot positions / velocities.
+constexpr int KC_M = 0, KC_X = 324, KC_LG = 540, KC_RDM = 684, KC_RDG = 702, KC_QDD = 714, KC_GRF = 732, KC_LAM = 744, KC_J = 756, KC_FP = 972, KC_FV = 984, KC_SIZE = 1024;
+
 // Per-phase device descriptor.  Trajectory arrays are [batch][count][elems] (problem-major, horizon-major,
 // element-contiguous, matrices column-major) so that one wave reads/writes a knot's record with unit stride.
 struct PhaseDev {
@@ -49,6 +54,7 @@ struct PhaseDev {
     double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
     double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
     double *g, *delta, *eps;                                           // h x ng
+    double* kc;                                                        // whole-body phases: contact-solve cache of the last rollout, h x KC_SIZE
     double *th, *sigma, *lambda;                                       // nt
 };
 

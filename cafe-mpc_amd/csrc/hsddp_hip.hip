@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, in
 }
 
 __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
-                                          const ProbState* st, int mask) {
+                                          const ProbState* st, int mask, int use_cache) {
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
     __shared__ WbLqLds L;
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, 
         if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
         return;
     }
-    if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active);
+    if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active, use_cache != 0);
     else wb_lq_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
 }
 
@@ -348,7 +348,7 @@ struct hsddp_handle {
     std::vector<void*> allocs;
     hipStream_t stream = nullptr;
     float solve_ms = 0;
-    bool rolled = false;
+    bool cache_valid = false;         // every problem has been rolled out since its trajectories were last set from outside: P.kc matches X, U
     // kernel timing
     std::vector<std::string> kname; std::vector<double> kms; std::vector<long long> kcnt;
     struct Ev { hipEvent_t a, b; int id; };
@@ -470,6 +470,7 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     if (!h || phase < 0 || phase >= h->nph) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
     PhaseDev& P = h->ph[phase]; const size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m, B = h->batch;
+    h->cache_valid = false;
     if (Xbar) {
         HIPCK(hipMemcpy(P.Xbar, Xbar, (per_problem ? B : 1) * sx * 8, hipMemcpyHostToDevice));
         if (!per_problem) dev_replicate(P.Xbar, sx * 8, B);
@@ -490,10 +491,12 @@ static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mas
     hipMemsetAsync(h->d_fail, 0, h->batch * sizeof(int), h->stream);
     hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md,
                        eps, o, h->d_x0, h->sa, h->d_st, mask, h->d_fail);
+    if (mask == MASK_NONE) h->cache_valid = true;     // masked launches only refresh problems whose cache was valid already
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_lq");
-    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask);
+    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
+                       h->cache_valid ? 1 : 0);
 }
 static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_cost");
@@ -645,6 +648,7 @@ float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h ? h->solve_ms : 0.f;
 int hsddp_warm_start_phase(hsddp_handle_t* dst, int dphase, hsddp_handle_t* src, int sphase, int shift) {
     if (!dst || dphase < 0 || dphase >= dst->nph || shift < 0) return HSDDP_EINVAL;
     const PhaseDev& D = dst->ph[dphase];
+    dst->cache_valid = false;
     const bool has = src != nullptr && sphase >= 0;
     if (has && (sphase >= src->nph || src->batch != dst->batch || src->device != dst->device || src->ph[sphase].model != D.model)) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(dst->device));

@@ -393,8 +393,11 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
         L.tmp[tid] = P.ur[(size_t)k * 12 + i]; L.red[tid] = P.Ubar[ku + i] + eps * P.dU[ku + i];
     } else if (tid < 60) L.tmp[tid] = P.foot_vel[(size_t)k * 12 + tid - 48];
       if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
-      for (int c = tid; c < P.ng; c += NT) { L.gval()[c] = P.eps[kk * P.ng + c]; L.bar()[c] = P.delta[kk * P.ng + c]; }
-      for (int i = tid; i < 432; i += NT) Kst[i] = P.K[kk * 432 + i];)
+      { double kr[7], er[2], dr[2];     // every global load of the lane issued before the first LDS store
+        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
+        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = kr[q]; }
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } } })
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
         double u = L.red[36 + tid] + s;
@@ -405,6 +408,15 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
     RL_STAMP(1)
     wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
     RL_STAMP(2)
+    {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
+        double* kc = P.kc + kk * KC_SIZE;
+        HS_PHASE_L(NT,
+            for (int i = tid; i < 324; i += NT) kc[KC_M + i] = L.M[i];
+            for (int i = tid; i < 216; i += NT) { kc[KC_X + i] = L.Xm()[i]; kc[KC_J + i] = L.Jall[i]; }
+            for (int i = tid; i < 144; i += NT) kc[KC_LG + i] = L.LG()[i];
+            if (tid < 18) { kc[KC_RDM + tid] = L.rdM[tid]; kc[KC_QDD + tid] = L.qdd[tid]; }
+            if (tid < 12) { kc[KC_RDG + tid] = L.rdG[tid]; kc[KC_GRF + tid] = L.grf[tid]; kc[KC_LAM + tid] = L.lam[tid]; kc[KC_FP + tid] = L.fpos[tid]; kc[KC_FV + tid] = L.fvel[tid]; })
+    }
     RL_STAMP(3)
     // integrate, defect of knot k+1 (and of knot 0 for the very first knot of phase 0), constraint values + barrier, cost terms:
     // one phase, every lane its own entries; the sums are taken afterwards in the reference's order by four lanes in parallel
@@ -603,7 +615,7 @@ HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dve
 
 // LQ approximation of knot k < h (recomputes the contact solve at the stored X,U like WBM.cpp:463)
 template <int NT>
-HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int k, int reb_active) {
+HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int k, int reb_active, bool cached = false) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
@@ -611,17 +623,37 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 12) { L.u[tid] = P.U[ku + tid]; L.fext[tid] = 0.0; }
              if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
              wb_cost_prefetch(L, P, k, tid);
-             for (int c = tid; c < P.ng; c += NT) {
-                 size_t gi = kk * P.ng + c; double g = P.g[gi], delta = P.delta[gi], e = P.eps[gi], bd, bdd;
-                 if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
-                 D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0;
+             { double gr[2], dr[2], er[2];
+               _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; const size_t gi = kk * P.ng + c; const bool in = c < P.ng; gr[q] = in ? P.g[gi] : 1.0; dr[q] = in ? P.delta[gi] : 1.0; er[q] = in ? P.eps[gi] : 0.0; }
+               _Pragma("unroll") for (int q = 0; q < 2; q++) {
+                   const int c = q * NT + tid; const double g = gr[q], delta = dr[q], e = er[q]; double bd, bdd;
+                   if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
+                   if (c < P.ng) { D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0; }
+               } }
+             if (cached) {   // the rollout that produced X[k], U[k] left its contact solve behind: fetch it (same phase as every other global
+                             // read of the knot) instead of repeating the terms and the factorisations
+                 const double* kc = P.kc + kk * KC_SIZE;
+                 double r[KC_SIZE / 64];      // a loop of load -> LDS store would pay the HBM latency once per trip: stage the whole record
+                 _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) r[q] = kc[q * 64 + tid];
+                 _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) {
+                     const int i = q * 64 + tid; const double v = r[q];
+                     if (i < KC_X) L.M[i] = v; else if (i < KC_LG) L.Xm()[i - KC_X] = v; else if (i < KC_RDM) D.LGs[i - KC_LG] = v;
+                     else if (i < KC_RDG) L.rdM[i - KC_RDM] = v; else if (i < KC_QDD) D.rdGs[i - KC_RDG] = v; else if (i < KC_GRF) L.qdd[i - KC_QDD] = v;
+                     else if (i < KC_LAM) L.grf[i - KC_GRF] = v; else if (i < KC_J) L.lam[i - KC_LAM] = v; else if (i < KC_FP) L.Jall[i - KC_J] = v;
+                     else if (i < KC_FV) L.fpos[i - KC_FP] = v; else if (i < KC_FV + 12) L.fvel[i - KC_FV] = v;
+                 }
              })
-    HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
     LQ_STAMP0()
-    wb_terms<NT>(L, md, true);
-    LQ_STAMP(0)
-    wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
-    wb_keep_schur<NT>(L, D);
+    if (cached) {
+        wb_trig<NT>(L);
+        LQ_STAMP(0)
+    } else {
+        HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
+        wb_terms<NT>(L, md, true);
+        LQ_STAMP(0)
+        wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
+        wb_keep_schur<NT>(L, D);
+    }
     LQ_STAMP(1)
     const int m = 3 * P.nc;
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid]; if (tid < 12) L.fext[tid] = L.grf[tid];)

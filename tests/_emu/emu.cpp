@@ -27,6 +27,7 @@ struct hsddp_handle {
     std::vector<int> fail;
     ModelDev md;
     std::vector<void*> allocs;
+    bool cache_valid = false;
 };
 struct HostMem {
     hsddp_handle* h;
@@ -56,6 +57,7 @@ void hsddp_destroy(hsddp_handle_t* h) { if (!h) return; for (void* p : h->allocs
 int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) { memcpy(h->x0.data(), x0, h->x0.size() * 8); return 0; }
 int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per) {
     PhaseDev& P = h->ph[phase]; size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m;
+    h->cache_valid = false;
     for (size_t b = 0; b < (size_t)h->batch; b++) {
         if (Xbar) { memcpy(P.Xbar + b * sx, Xbar + (per ? b * sx : 0), sx * 8); memcpy(P.X + b * sx, Xbar + (per ? b * sx : 0), sx * 8); }
         if (Ubar) { memcpy(P.Ubar + b * su, Ubar + (per ? b * su : 0), su * 8); memcpy(P.U + b * su, Ubar + (per ? b * su : 0), su * 8); }
@@ -92,6 +94,7 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
         double c = 0, d = 0; for (int s = 0; s < h->nslots; s++) { c += h->cost[(size_t)b * h->nslots + s]; d += h->dsq[(size_t)b * h->nslots + s]; }
         h->acost[b] = c; h->feas[b] = sqrt(d);
     }
+    h->cache_valid = true;
     return 0;
 }
 int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }
@@ -101,7 +104,7 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
         int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
         if (P.model == HSDDP_MODEL_HKD) { if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, o.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active); }
         else if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
-        else if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active);
+        else if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active, h->cache_valid);
         else wb_lq_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
     }
     return 0;
