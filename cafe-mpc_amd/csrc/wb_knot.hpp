@@ -383,21 +383,24 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
     // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five): the references and the
     // barrier parameters wait in LDS (tmp / red / the tail of GG) until the phases that use them
     const size_t kk = (size_t)b * h + k;
-    HS_PHASE(NT, if (tid < 36) {
-        double xb = P.Xbar[kx + tid], x = ss ? L.xnext[tid] : xb + eps * P.dX[kx + tid];
-        L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
-        L.tmp[tid] = P.xr[(size_t)k * 36 + tid];
-        L.red[tid] = ss ? 0.0 : P.Xbar[kx + 36 + tid] + eps * P.dX[kx + 36 + tid];
-    } else if (tid < 48) {
-        const int i = tid - 36;
-        L.tmp[tid] = P.ur[(size_t)k * 12 + i]; L.red[tid] = P.Ubar[ku + i] + eps * P.dU[ku + i];
-    } else if (tid < 60) L.tmp[tid] = P.foot_vel[(size_t)k * 12 + tid - 48];
-      if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
-      { double kr[7], er[2], dr[2];     // every global load of the lane issued before the first LDS store
+    HS_PHASE(NT,
+        double va = 0, vb = 0, vc = 0, vd = 0, ve = 0;
+        if (tid < 36) { va = P.Xbar[kx + tid]; vb = P.dX[kx + tid]; vc = P.xr[(size_t)k * 36 + tid]; if (!ss) { vd = P.Xbar[kx + 36 + tid]; ve = P.dX[kx + 36 + tid]; } }
+        else if (tid < 48) { const int i = tid - 36; vc = P.ur[(size_t)k * 12 + i]; vd = P.Ubar[ku + i]; ve = P.dU[ku + i]; }
+        else if (tid < 60) vc = P.foot_vel[(size_t)k * 12 + tid - 48];
+        double kr[7], er[2], dr[2];
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
+        HS_CBAR();
+        if (tid < 36) {
+            const double xb = va, x = ss ? L.xnext[tid] : xb + eps * vb;
+            L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
+            L.tmp[tid] = vc; L.red[tid] = ss ? 0.0 : vd + eps * ve;
+        } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
+        else if (tid < 60) L.tmp[tid] = vc;
+        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = kr[q]; }
-        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } } })
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
         double u = L.red[36 + tid] + s;
@@ -620,30 +623,41 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
     // the barrier derivative tables only need g, delta, eps of the rollout: their global loads are issued together with x, u
-    HS_PHASE(NT, if (tid < 36) L.x[tid] = P.X[kx + tid]; if (tid < 12) { L.u[tid] = P.U[ku + tid]; L.fext[tid] = 0.0; }
-             if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
-             wb_cost_prefetch(L, P, k, tid);
-             { double gr[2], dr[2], er[2];
-               _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; const size_t gi = kk * P.ng + c; const bool in = c < P.ng; gr[q] = in ? P.g[gi] : 1.0; dr[q] = in ? P.delta[gi] : 1.0; er[q] = in ? P.eps[gi] : 0.0; }
-               _Pragma("unroll") for (int q = 0; q < 2; q++) {
-                   const int c = q * NT + tid; const double g = gr[q], delta = dr[q], e = er[q]; double bd, bdd;
-                   if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
-                   if (c < P.ng) { D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0; }
-               } }
-             if (cached) {   // the rollout that produced X[k], U[k] left its contact solve behind: fetch it (same phase as every other global
-                             // read of the knot) instead of repeating the terms and the factorisations
-                 const double* kc = P.kc + kk * KC_SIZE;
-                 double r[KC_SIZE / 64];      // a loop of load -> LDS store would pay the HBM latency once per trip: stage the whole record
-                 _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) r[q] = kc[q * 64 + tid];
-                 _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) {
-                     const int i = q * 64 + tid; const double v = r[q];
-                     if (i < KC_X) L.M[i] = v; else if (i < KC_LG) L.Xm()[i - KC_X] = v; else if (i < KC_RDM) D.LGs[i - KC_LG] = v;
-                     else if (i < KC_RDG) L.rdM[i - KC_RDM] = v; else if (i < KC_QDD) D.rdGs[i - KC_RDG] = v; else if (i < KC_GRF) L.qdd[i - KC_QDD] = v;
-                     else if (i < KC_LAM) L.grf[i - KC_GRF] = v; else if (i < KC_J) L.lam[i - KC_LAM] = v; else if (i < KC_FP) L.Jall[i - KC_J] = v;
-                     else if (i < KC_FV) L.fpos[i - KC_FP] = v; else if (i < KC_FV + 12) L.fvel[i - KC_FV] = v;
-                 }
-             })
     LQ_STAMP0()
+    HS_PHASE(NT,
+        // ---- every global read of the knot first (one exposed HBM round trip), the LDS stores afterwards
+        const double vx = (tid < 36) ? P.X[kx + tid] : 0.0, vu = (tid < 12) ? P.U[ku + tid] : 0.0;
+        const double vt = (tid < 36) ? P.xr[(size_t)k * 36 + tid] : (tid < 48) ? P.ur[(size_t)k * 12 + tid - 36] : 0.0;
+        const double vf = (tid < 12) ? P.foot_pos[(size_t)k * 12 + tid] : (tid < 15) ? P.body_pos[(size_t)k * 3 + tid - 12] : (tid < 19) ? (double)P.ref_contact[(size_t)k * 4 + tid - 15] : 0.0;
+        const double vv = (tid < 12) ? P.foot_vel[(size_t)k * 12 + tid] : 0.0;
+        double gr[2], dr[2], er[2];
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; const size_t gi = kk * P.ng + c; const bool in = c < P.ng; gr[q] = in ? P.g[gi] : 1.0; dr[q] = in ? P.delta[gi] : 1.0; er[q] = in ? P.eps[gi] : 0.0; }
+        double r[KC_SIZE / 64];
+        if (cached) {   // the rollout that produced X[k], U[k] left its contact solve behind: fetch it instead of repeating the terms and the factorisations
+            const double* kc = P.kc + kk * KC_SIZE;
+            _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) r[q] = kc[q * 64 + tid];
+        }
+        HS_CBAR();
+        if (tid < 36) L.x[tid] = vx; if (tid < 12) { L.u[tid] = vu; L.fext[tid] = 0.0; }
+        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
+        // cost references (layout of wb_cost_prefetch): tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
+        if (tid < 48) L.tmp[tid] = vt;
+        if (tid < 12) { L.red[tid] = vf; L.red[12 + tid] = vv; } else if (tid < 15) L.red[12 + tid] = vf; else if (tid < 19) L.red[13 + tid] = vf;
+        _Pragma("unroll") for (int q = 0; q < 2; q++) {
+            const int c = q * NT + tid; const double g = gr[q], delta = dr[q], e = er[q]; double bd, bdd;
+            if (g > delta) { bd = -1.0 / g; bdd = 1.0 / (g * g); } else { bd = (g - 2 * delta) / delta / delta; bdd = 1.0 / (delta * delta); }
+            if (c < P.ng) { D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0; }
+        }
+        if (cached) {
+            _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) {
+                const int i = q * 64 + tid; const double v = r[q];
+                if (i < KC_X) L.M[i] = v; else if (i < KC_LG) L.Xm()[i - KC_X] = v; else if (i < KC_RDM) D.LGs[i - KC_LG] = v;
+                else if (i < KC_RDG) L.rdM[i - KC_RDM] = v; else if (i < KC_QDD) D.rdGs[i - KC_RDG] = v; else if (i < KC_GRF) L.qdd[i - KC_QDD] = v;
+                else if (i < KC_LAM) L.grf[i - KC_GRF] = v; else if (i < KC_J) L.lam[i - KC_LAM] = v; else if (i < KC_FP) L.Jall[i - KC_J] = v;
+                else if (i < KC_FV) L.fpos[i - KC_FP] = v; else if (i < KC_FV + 12) L.fvel[i - KC_FV] = v;
+            }
+        })
+    LQ_STAMP(11)
     if (cached) {
         wb_trig<NT>(L);
         LQ_STAMP(0)

@@ -42,7 +42,7 @@ elif hasattr(lib, "hsddp_debug_lq_prof"):
     s.LQ_approximation(opt)
     lib.hsddp_debug_lq_prof(buf, 0)
     names = ["terms(P pass)", "kkt_direct + keep", "dpass", "A/C columns", "store A,B,C,D", "cost partials lxx", "lu/luu/ly/lyy",
-             "kkt: select", "kkt: chol M", "kkt: X, y, gram", "kkt: chol G"]
+             "kkt: select", "kkt: chol M", "kkt: X, y, gram", "kkt: chol G", "load phase"]
     tot = sum(buf)
     for i, n in enumerate(names):
         print(f"  lq stamp {i} {n:20s} {buf[i]:10d} cycles ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
