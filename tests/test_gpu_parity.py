@@ -353,6 +353,21 @@ def test_mpc_command_export(hip_lib, oracle_lib):
         sm.export_mpc_command(n_steps=8)           # only 6 whole-body control knots exist
 
 
+def test_lq_without_a_preceding_rollout(hip_lib, oracle_lib):
+    """The LQ approximation normally fetches the contact solve its rollout cached; straight after hsddp_set_nominal there is no such
+    rollout and the kernel must recompute everything (value tasks + factorisations): same dynamics partials as the oracle."""
+    phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+    x0 = pkg.problems.wb_ensemble_x0(2, 41)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    opt = pkg.mhpc_ddp_setting()
+    for s_ in (so, sg):
+        s_.LQ_approximation(opt)
+    pc.compare(so, sg, ["A", "B", "C", "D"], len(phases), 1e-8, "lq_uncached")
+    for s_ in (so, sg):                       # and the cached path right after, on the same state
+        s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.LQ_approximation(opt)     # compute_cost zeroes the oracle's cost partials (quirk ii)
+    pc.compare(so, sg, pc.STEP_FIELDS["lq"], len(phases), 1e-8, "lq_cached")
+
+
 def test_unsupported_configurations_fail_loudly(hip_lib):
     import ctypes
     phases = pkg.problems.wb_stance_problem(horizon=3)
