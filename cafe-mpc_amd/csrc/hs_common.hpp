@@ -39,6 +39,15 @@ template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("
 #define HS_WPHASE(...) { if (threadIdx.x < 64) { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
+// Trajectory pointers live in descriptors that the kernels read from memory, so the compiler cannot see that they point to global
+// memory and would emit FLAT loads / stores (which also count on lgkmcnt: every LDS wait then drains them).  HS_GLOBAL pins the
+// address space in device code; on the host (and in the lane emulator) it is an ordinary pointer of the same size.
+#if !defined(HS_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define HS_GLOBAL __attribute__((address_space(1)))
+#else
+#define HS_GLOBAL
+#endif
+
 // compiler-only memory barrier: stops the scheduler from hoisting a whole unrolled recurrence's LDS loads ahead of it
 // (hundreds of live registers); emits no instruction
 #define HS_CBAR() asm volatile("" ::: "memory")

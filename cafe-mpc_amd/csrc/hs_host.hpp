@@ -8,6 +8,7 @@
 #include "hsddp.h"
 #include "hs_types.hpp"
 
+#if !defined(__HIP_DEVICE_COMPILE__)   // host only: the device pass sees address-space qualified descriptor pointers (HS_GLOBAL)
 namespace hs {
 
 // reset maps that exist in the reference: WB->WB, WB->SRB (MHPCReset.cpp:4-52), SRB->SRB (identity), HKD->HKD (HKDReset.h)
@@ -139,3 +140,4 @@ inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems,
 }
 
 }  // namespace hs
+#endif

@@ -39,23 +39,23 @@ struct PhaseDev {
     int nt;                                           // terminal constraints (touchdown feet)
     int slot0;                                        // first global slot of this phase (slots = h+1 per phase)
     // reference arrays shared by the batch: (h+1) x width
-    const double *xr, *ur, *yr, *foot_pos, *foot_vel, *body_pos;
-    const int* ref_contact;
+    const HS_GLOBAL double *xr, *ur, *yr, *foot_pos, *foot_vel, *body_pos;
+    const HS_GLOBAL int* ref_contact;
     // trajectories
-    double *X, *Xbar, *Xsim, *Defect, *Defect_bar, *dX, *G;           // (h+1) x n
-    double *U, *Ubar, *dU, *Qu;                                        // h x m
-    double *Y;                                                         // h x p
-    double *K, *Qux, *Quu;                                             // h x (m*n), h x (m*m)
-    double *A, *B, *C, *D;                                             // h x ...
+    HS_GLOBAL double *X, *Xbar, *Xsim, *Defect, *Defect_bar, *dX, *G;           // (h+1) x n
+    HS_GLOBAL double *U, *Ubar, *dU, *Qu;                                        // h x m
+    HS_GLOBAL double *Y;                                                         // h x p
+    HS_GLOBAL double *K, *Qux, *Quu;                                             // h x (m*n), h x (m*m)
+    HS_GLOBAL double *A, *B, *C, *D;                                             // h x ...
     // LQ record of a knot: ONE contiguous block per (problem, knot) of `rs` doubles holding A | lxx | B | C | D | luu | lyy |
     // lx lu ly, each sub-array starting at a multiple of 256 doubles (REC_* offsets), so that the Riccati workgroup
     // streams a knot with one base pointer and unit stride.  A, lxx, ... below point INTO rec: element e of knot kk is P.A[kk*rs + e].
-    double* rec; int rs;
-    double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
-    double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
-    double *g, *delta, *eps;                                           // h x ng
-    double* kc;                                                        // whole-body phases: contact-solve cache of the last rollout, h x KC_SIZE
-    double *th, *sigma, *lambda;                                       // nt
+    HS_GLOBAL double* rec; int rs;
+    HS_GLOBAL double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
+    HS_GLOBAL double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
+    HS_GLOBAL double *g, *delta, *eps;                                           // h x ng
+    HS_GLOBAL double* kc;                                                        // whole-body phases: contact-solve cache of the last rollout, h x KC_SIZE
+    HS_GLOBAL double *th, *sigma, *lambda;                                       // nt
 };
 
 // ReB parameter group of path constraint c (index into reb_init)

@@ -333,6 +333,7 @@ __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+#if !defined(__HIP_DEVICE_COMPILE__)   // the device pass sees address-space qualified descriptor pointers (HS_GLOBAL)
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 
 struct hsddp_handle {
@@ -707,3 +708,4 @@ int hsddp_debug_sweep_prof(unsigned long long* out16, int reset) {
 int hsddp_reset_kernel_times(hsddp_handle_t* h) { if (!h) return HSDDP_EINVAL; for (auto& v : h->kms) v = 0; for (auto& v : h->kcnt) v = 0; return HSDDP_OK; }
 
 }  // extern "C"
+#endif
