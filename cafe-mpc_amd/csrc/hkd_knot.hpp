@@ -68,7 +68,7 @@ HD double hkd_grf_row(const double* u, int f, int r, double mu) {
     return r == 0 ? fz : r == 1 ? -fx + mu * fz : r == 2 ? fx + mu * fz : r == 3 ? -fy + mu * fz : fy + mu * fz;
 }
 // sum_f,a d (c_f w_a) d of the foot-placement regulariser (HKDCost.cpp:4-19) at knot k
-HD double hkd_footreg(const PhaseDev& P, const double* x, int k) {
+HD double hkd_footreg(PhaseC& P, const double* x, int k) {
     const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
     double s = 0;
     for (int f = 0; f < 4; f++) for (int a = 0; a < 3; a++) { const double d = (x[12 + 3 * f + a] - x[3 + a]) - (fp[3 * f + a] - bp[a]); s += d * (P.contact[f] * P.w_foot_reg[a]) * d; }
@@ -76,7 +76,7 @@ HD double hkd_footreg(const PhaseDev& P, const double* x, int k) {
 }
 
 template <int NT>
-HD void hkd_rollout_knot(HkdLds& L, const PhaseDev& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
+HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 24, ku = ((size_t)b * h + k) * 24, kk = (size_t)b * h + k;
     HS_PHASE(NT, if (tid < 24) { double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; }
@@ -125,7 +125,7 @@ HD void hkd_rollout_knot(HkdLds& L, const PhaseDev& P, int b, int k, double eps,
 // Terminal knot of an HKD phase: terminal cost, touchdown constraint (foot height of the legs about to land), reset map
 // (HKDReset.h:41-76: lift-off -> default joint angles, touchdown -> foot projected on the ground) into the next phase.
 template <int NT>
-HD void hkd_rollout_terminal(HkdLds& L, const PhaseDev& P, const PhaseDev* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot) {
+HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 24;
     HS_PHASE(NT, if (tid < 24) { const double x = P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
@@ -167,7 +167,7 @@ HD void hkd_rollout_terminal(HkdLds& L, const PhaseDev& P, const PhaseDev* Pn, c
 // LQ approximation of HKD knot k < h.  32 forward-mode lanes (12 body states, 8 stance-foot x/y, 12 forces) give the body
 // rows of [A B]; the qdummy rows are the identity plus dt (1 - c_l) on the joint-velocity inputs.
 template <int NT>
-HD void hkd_lq_knot(HkdLds& L, const PhaseDev& P, int b, int k, int reb_active) {
+HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 24, ku = ((size_t)b * h + k) * 24, kk = (size_t)b * h + k;
     double* AB = L.K;   // [row 0..11][lane 0..31]
@@ -240,7 +240,7 @@ HD void hkd_lq_knot(HkdLds& L, const PhaseDev& P, int b, int k, int reb_active) 
 
 // Terminal partials of an HKD phase (+ AL on the touchdown heights) and the reset-map partial Px (HKDReset.h:78-136).
 template <int NT>
-HD void hkd_lq_terminal(HkdLds& L, const PhaseDev& P, const PhaseDev* Pn, const ModelDev& md, int b, int al_active) {
+HD void hkd_lq_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, int al_active) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 24;
     HS_PHASE(NT, if (tid < 24) L.x[tid] = P.X[kx + tid]; for (int i = tid; i < 96; i += NT) L.hx[i] = 0.0; for (int i = tid; i < 108; i += NT) L.J[i] = 0.0;)

@@ -42,11 +42,18 @@ template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("
 // Trajectory pointers live in descriptors that the kernels read from memory, so the compiler cannot see that they point to global
 // memory and would emit FLAT loads / stores (which also count on lgkmcnt: every LDS wait then drains them).  HS_GLOBAL pins the
 // address space in device code; on the host (and in the lane emulator) it is an ordinary pointer of the same size.
+// The descriptors themselves are written by the host before a launch and never by a kernel: reading them through the CONSTANT
+// address space (HS_CONST) lets the compiler fetch their fields with scalar loads and keep them across memory clobbers instead
+// of re-reading each field with an exposed vector load after every phase boundary.
 #if !defined(HS_HOST_EMU) && defined(__HIP_DEVICE_COMPILE__)
 #define HS_GLOBAL __attribute__((address_space(1)))
+#define HS_CONST __attribute__((address_space(4)))
 #else
 #define HS_GLOBAL
+#define HS_CONST
 #endif
+// generic pointer that the optimiser knows to point into constant memory (address-space inference follows the double cast)
+#define HS_AS_CONST(T, p) ((const T*)(const HS_CONST T*)(p))
 
 // compiler-only memory barrier: stops the scheduler from hoisting a whole unrolled recurrence's LDS loads ahead of it
 // (hundreds of live registers); emits no instruction

@@ -58,6 +58,9 @@ struct PhaseDev {
     HS_GLOBAL double *th, *sigma, *lambda;                                       // nt
 };
 
+// how device code sees a descriptor: constant memory (scalar loads, values survive memory clobbers)
+using PhaseC = const HS_CONST PhaseDev;
+
 // ReB parameter group of path constraint c (index into reb_init)
 HDH int constraint_group(const PhaseDev& P, int c) {
     if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) return 0;

@@ -46,13 +46,14 @@ __device__ inline bool masked_out(const ProbState& s, int mask) {
     return false;
 }
 
-__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
+__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
                                                double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail) {
+    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
     __shared__ WbCore L;
     const int pi = slot_phase[s], k = slot_k[s];
-    const PhaseDev& P = ph[pi];
+    PhaseC& P = ph[pi];
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
     const size_t slot = (size_t)b * nslots + s;
     if (P.model == HSDDP_MODEL_HKD) {
@@ -72,20 +73,21 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph, in
     else {
         wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
         for (int pj = pi + 1; pj < nph && !ph[pj].shooting; pj++) {      // single-shooting chain (young phases of the receding-horizon update)
-            const PhaseDev& Q = ph[pj]; const size_t s0 = (size_t)b * nslots + Q.slot0;
+            PhaseC& Q = ph[pj]; const size_t s0 = (size_t)b * nslots + Q.slot0;
             for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
             wb_rollout_terminal<64>(L, Q, pj + 1 < nph ? &ph[pj + 1] : nullptr, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
         }
     }
 }
 
-__global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
+__global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
                                           const ProbState* st, int mask, int use_cache) {
+    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
     __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
-    const PhaseDev& P = ph[pi];
+    PhaseC& P = ph[pi];
     if (P.model == HSDDP_MODEL_HKD) {
         HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
         if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
@@ -101,12 +103,13 @@ __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph, int nph, 
 }
 
 // cost-only refresh from stored g / h with the CURRENT ReB / AL parameters (SinglePhase::compute_cost, SinglePhase.cpp:236-262)
-__global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph, const int* slot_phase, const int* slot_k, int nslots, OptDev opt, SlotArrays sa,
+__global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, int nslots, OptDev opt, SlotArrays sa,
                                             const ProbState* st, int mask) {
+    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
     __shared__ double bar[MAXG];
-    const PhaseDev& P = ph[slot_phase[s]]; const int k = slot_k[s]; const int tid = threadIdx.x;
+    PhaseC& P = ph[slot_phase[s]]; const int k = slot_k[s]; const int tid = threadIdx.x;
     const size_t slot = (size_t)b * nslots + s;
     if (k < P.h) {
         const size_t kk = (size_t)b * P.h + k;
@@ -128,8 +131,9 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph, const int* slot
     }
 }
 
-__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
+__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
                                                 int do_linear, double lin_eps, int* success_out) {
+    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x;
     if (masked_out(st[b], mask)) return;
     __shared__ SweepLds S;
@@ -154,7 +158,8 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph, in
     if (threadIdx.x == 0) { st[b].dV_1 = S.c.dV1; st[b].dV_2 = S.c.dV2; }
 }
 
-__global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph, int nph, ProbState* st, double eps) {
+__global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
+    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     __shared__ SweepLds S;
     linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
     __syncthreads();

@@ -54,7 +54,7 @@ struct SrbLds {
 
 // Rollout of one SRB knot k < h of problem b (SinglePhase::forward_sweep body with the SRB callbacks).
 template <int NT>
-HD void srb_rollout_knot(SrbLds& L, const PhaseDev& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
+HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 12, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
     HS_PHASE(NT, if (tid < 12) { double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; }
@@ -95,7 +95,7 @@ HD void srb_rollout_knot(SrbLds& L, const PhaseDev& P, int b, int k, double eps,
 
 // Terminal knot of an SRB phase: quadratic terminal cost; the reset map to a following SRB phase is the identity.
 template <int NT>
-HD void srb_rollout_terminal(SrbLds& L, const PhaseDev& P, const PhaseDev* Pn, int b, double eps, SlotOut so, size_t slot) {
+HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps, SlotOut so, size_t slot) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 12;
     HS_PHASE(NT, if (tid < 12) { const double x = P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
@@ -118,7 +118,7 @@ HD void srb_rollout_terminal(SrbLds& L, const PhaseDev& P, const PhaseDev* Pn, i
 
 // LQ approximation of SRB knot k < h: A = I + dt df/dx, B = dt df/du (SRBM.h:70-93), tracking cost + height barrier.
 template <int NT>
-HD void srb_lq_knot(SrbLds& L, const PhaseDev& P, int b, int k, int reb_active) {
+HD void srb_lq_knot(SrbLds& L, PhaseC& P, int b, int k, int reb_active) {
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 12, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
     HS_PHASE(NT, if (tid < 12) { L.x[tid] = P.X[kx + tid]; L.u[tid] = P.U[ku + tid]; })
@@ -151,7 +151,7 @@ HD void srb_lq_knot(SrbLds& L, const PhaseDev& P, int b, int k, int reb_active) 
 
 // Terminal partials of an SRB phase; Px = I (12 x 12) when another SRB phase follows.
 template <int NT>
-HD void srb_lq_terminal(SrbLds& L, const PhaseDev& P, const PhaseDev* Pn, int b) {
+HD void srb_lq_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 12;
     HS_PHASE(NT, if (tid < 12) P.Phix[(size_t)b * 12 + tid] = P.qf[tid] * (P.X[kx + tid] - P.xr[(size_t)h * 12 + tid]);

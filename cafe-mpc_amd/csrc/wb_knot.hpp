@@ -353,7 +353,7 @@ HD double reb_barrier(double g, double delta) {   // ConstraintsBase.h:238-245
 }
 
 // path-constraint value c (order: torque 24, joint 24, height 1, grf 5/foot) — MHPCConstraint.cpp
-HD double wb_constraint(const PhaseDev& P, const WbCore& L, int c) {
+HD double wb_constraint(PhaseC& P, const WbCore& L, int c) {
     if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) { int i = c - P.go_torque; return i < 12 ? -L.u[i] + P.torque_limit : L.u[i - 12] + P.torque_limit; }
     if (P.go_jspeed >= 0 && c >= P.go_jspeed && c < P.go_jspeed + 24) { int i = c - P.go_jspeed; return i < 12 ? L.x[24 + i] - P.jspeed_lb : -L.x[24 + i - 12] + P.jspeed_ub; }
     if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) { int i = c - P.go_joint; return i < 12 ? L.x[6 + i] - P.joint_lb[i % 3] : -L.x[6 + i - 12] + P.joint_ub[i % 3]; }
@@ -372,7 +372,7 @@ struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // 
 // -------------------------------------------------------------------------------------------------------
 // Rollout of one knot k < h of problem b.   eps: line-search step.
 template <int NT>
-HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b, int k, double eps, int reb_active,
+HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, double eps, int reb_active,
                         const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
     // ss: knot of a phase WITHOUT shooting nodes (SS_set empty, a phase the receding-horizon update has just created,
     // MHPCProblem.cpp:340-351): X[k] is the simulated state handed over in L.xnext, X[k+1] = Xsim[k+1], the defect is zero
@@ -487,7 +487,7 @@ HD void wb_rollout_knot(WbCore& L, const PhaseDev& P, const ModelDev& md, int b,
 }
 
 // terminal cost without AL (tracking + foot-place reg (x1) + touchdown-velocity penalty). MHPCCost.cpp:67-87,255-268
-HD double wb_terminal_cost_base(const PhaseDev& P, const WbCore& L) {
+HD double wb_terminal_cost_base(PhaseC& P, const WbCore& L) {
     const int h = P.h;
     double s = 0; for (int i = 0; i < 36; i++) { double d = L.x[i] - P.xr[(size_t)h * 36 + i]; s += d * P.qf[i] * d; }
     double Phi = 0.5 * s;
@@ -503,7 +503,7 @@ HD double wb_terminal_cost_base(const PhaseDev& P, const WbCore& L) {
 
 // Terminal knot (k = h) of a phase: terminal constraint + cost, then the reset map into the next phase.
 template <int NT>
-HD void wb_rollout_terminal(WbCore& L, const PhaseDev& P, const PhaseDev* Pn, const ModelDev& md, int b, double eps, int al_active,
+HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active,
                             SlotOut so, size_t slot, bool ss = false) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 36;
@@ -549,7 +549,7 @@ template <int NT> HD void store_block(double* dst, const double* src, int n) { H
 
 // References of knot k for the cost partials, fetched with the state so that no later phase waits on HBM:
 //   tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
-HD void wb_cost_prefetch(WbCore& L, const PhaseDev& P, int k, int tid) {
+HD void wb_cost_prefetch(WbCore& L, PhaseC& P, int k, int tid) {
     if (tid < 36) L.tmp[tid] = P.xr[(size_t)k * 36 + tid];
     else if (tid < 48) L.tmp[tid] = P.ur[(size_t)k * 12 + tid - 36];
     if (tid < 12) { L.red[tid] = P.foot_pos[(size_t)k * 12 + tid]; L.red[12 + tid] = P.foot_vel[(size_t)k * 12 + tid]; }
@@ -560,7 +560,7 @@ HD void wb_cost_prefetch(WbCore& L, const PhaseDev& P, int k, int tid) {
 // JW (velocity-type rows [d vel/dq | J]), with per-row weights (dt folded in) and residuals.  `terminal` selects the
 // terminal cost objects (foot-place reg x2, touchdown velocity) instead of the running ones.
 template <int NT>
-HD void wb_cost_blocks(WbLqLds& S, const PhaseDev& P, int k, bool terminal) {
+HD void wb_cost_blocks(WbLqLds& S, PhaseC& P, int k, bool terminal) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const double* rc = L.red + 28; const double* fp = L.red; const double* bp = L.red + 24;     // wb_cost_prefetch
     (void)k;
@@ -618,7 +618,7 @@ HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dve
 
 // LQ approximation of knot k < h (recomputes the contact solve at the stored X,U like WBM.cpp:463)
 template <int NT>
-HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int k, int reb_active, bool cached = false) {
+HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int reb_active, bool cached = false) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int h = P.h; const double dt = P.dt;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
@@ -766,7 +766,7 @@ HD void wb_lq_knot(WbLqLds& S, const PhaseDev& P, const ModelDev& md, int b, int
 
 // Terminal partials of a phase (+ AL) and the reset-map partial Px (next_n x 36, column-major) if a phase follows.
 template <int NT>
-HD void wb_lq_terminal(WbLqLds& S, const PhaseDev& P, const PhaseDev* Pn, const ModelDev& md, int b, int al_active) {
+HD void wb_lq_terminal(WbLqLds& S, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, int al_active) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 36;
