@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slo
 
 __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
                                                 int do_linear, double lin_eps, int* success_out) {
-    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
+    const PhaseDev* ph = ph_;   // (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there)
     const int b = blockIdx.x;
     if (masked_out(st[b], mask)) return;
     __shared__ SweepLds S;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, i
 }
 
 __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
-    PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
+    const PhaseDev* ph = ph_;
     __shared__ SweepLds S;
     linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
     __syncthreads();

@@ -196,7 +196,7 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
-HD bool riccati_phase(SweepLds& SS, PhaseC& P, int b, double reg) {
+HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M, "sweep limits");
     constexpr int LDN = ST::LDN, LDM = ST::LDM;
@@ -293,10 +293,10 @@ HD bool riccati_phase(SweepLds& SS, PhaseC& P, int b, double reg) {
 // returns success, writes dV into S.c.dV1/dV2.  H of the phase being processed sits at the start of the raw block with
 // ld n+1 in every view; the gradient G crosses phase boundaries through S.c.xfer.
 template <int NT>
-HD bool riccati_sweep(SweepLds& S, PhaseC* ph, int nph, int b, double reg) {
+HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
-        PhaseC& P = ph[i];
+        const PhaseDev& P = ph[i];
         const int n = P.n;
         if (i == nph - 1) {
             HS_PHASE(NT, for (int e = tid; e < (n + 1) * n; e += NT) S.raw[e] = 0.0; if (tid < n) S.c.xfer[tid] = 0.0;)
@@ -351,7 +351,7 @@ HD bool riccati_sweep(SweepLds& S, PhaseC* ph, int nph, int b, double reg) {
 // dx+ = A dx + B du + eps defect together with the commit of the next knot's record into the other set.  The contributions to
 // dV_1 / dV_2 stay in registers (one partial sum per lane) and are added up once per phase.
 template <int NT, int N, int M, int PY>
-HD void linear_phase(SweepLds& SS, PhaseC& P, int b, double eps) {
+HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
     static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && N <= 64 && M <= 64, "prefetch registers / lane maps");
     static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(double), "the partial-sum scratch must not reach dx");
@@ -412,12 +412,12 @@ HD void linear_phase(SweepLds& SS, PhaseC& P, int b, double eps) {
 
 // linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
 template <int NT>
-HD void linear_rollout(SweepLds& S, PhaseC* ph, int nph, int b, double eps) {
+HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; } if (tid < SW_N) S.c.xfer[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
-        PhaseC& P = ph[i];
+        const PhaseDev& P = ph[i];
         if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); xfer holds the previous phase's terminal dX
-            PhaseC& Pp = ph[i - 1]; const int np = Pp.n, n = P.n;
+            const PhaseDev& Pp = ph[i - 1]; const int np = Pp.n, n = P.n;
             const double* Pxg = Pp.Px + (size_t)b * n * np;
             HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += Pxg[tid + n * t] * S.c.xfer[t]; S.raw[tid] = s; })
             HS_PHASE(NT, if (tid < n) S.c.xfer[tid] = S.raw[tid];)
