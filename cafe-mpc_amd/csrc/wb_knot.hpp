@@ -546,6 +546,23 @@ HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md
 // -------------------------------------------------------------------------------------------------------
 // coalesced copy LDS -> global
 template <int NT> HD void store_block(double* dst, const double* src, int n) { HS_PHASE_L(NT, for (int i = tid; i < n; i += NT) dst[i] = src[i];) }
+// Copy-out of a CNT-element image whose element e = r + ROWS*c is produced by f(e, r, c) (LDS reads / constants): fully unrolled, every
+// read is issued before the first store, (r, c) follow e = tid + NT*q without a division.  One wave; no barrier inside.
+template <int NT, int CNT, int ROWS, class DST, class F>
+HD void store_image(DST dst, int tid, F f) {
+    constexpr int R = (CNT + NT - 1) / NT;
+    const int c0 = tid / ROWS, r0 = tid - ROWS * c0;
+    double v[R];
+    _Pragma("unroll")
+    for (int q = 0; q < R; q++) {
+        const int e = tid + NT * q; int r = r0 + (NT * q) % ROWS, c = c0 + (NT * q) / ROWS;
+        if (r >= ROWS) { r -= ROWS; c++; }
+        v[q] = 0.0;
+        if (R * NT == CNT || e < CNT) v[q] = f(e, r, c);
+    }
+    _Pragma("unroll")
+    for (int q = 0; q < R; q++) { const int e = tid + NT * q; if (R * NT == CNT || e < CNT) dst[e] = v[q]; }
+}
 
 // References of knot k for the cost partials, fetched with the state so that no later phase waits on HBM:
 //   tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
@@ -707,14 +724,11 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     })
     LQ_STAMP(3)
     // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
-    HS_PHASE_L(NT, for (int e = tid; e < 1296; e += NT) {
-        const int r = e % 36, c = e / 36;
-        P.A[kk * P.rs + e] = (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c];
-    })
-    store_block<NT>(P.C + kk * P.rs, D.stC(), 432);
     HS_PHASE_L(NT,
-        for (int e = tid; e < 432; e += NT) { const int r = e % 36, j = e / 36; P.B[kk * P.rs + e] = (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; }
-        for (int e = tid; e < 144; e += NT) P.D[kk * P.rs + e] = D.stD()[e];)
+        store_image<NT, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
+        store_image<NT, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
+        store_image<NT, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
+        store_image<NT, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
     LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
@@ -736,7 +750,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         D.W[d * 36 + d] += diag;
         P.lx[kk * P.rs + d] = lxd;
     })
-    HS_PHASE_L(NT, for (int e = tid; e < 1296; e += NT) { const int r = e % 36, c = e / 36; P.lxx[kk * P.rs + e] = D.W[r * 36 + c]; })
+    HS_PHASE_L(NT, store_image<NT, 1296, 36>(P.lxx + kk * P.rs, tid, [&](int, int r, int c) { return D.W[r * 36 + c]; });)
     LQ_STAMP(5)
     // lu, luu (diag + torque barrier), ly, lyy (grf barrier 3x3 blocks) staged in Cst (288 of 432)
     HS_PHASE_L(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
@@ -759,8 +773,8 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         }
         P.ly[kk * P.rs + i] = dt * ly;
     })
-    store_block<NT>(P.luu + kk * P.rs, L.Jc(), 144);
-    store_block<NT>(P.lyy + kk * P.rs, L.Jc() + 144, 144);
+    HS_PHASE_L(NT, store_image<NT, 144, 12>(P.luu + kk * P.rs, tid, [&](int e, int, int) { return L.Jc()[e]; });
+                   store_image<NT, 144, 12>(P.lyy + kk * P.rs, tid, [&](int e, int, int) { return L.Jc()[144 + e]; });)
     LQ_STAMP(6)
 }
 
