@@ -154,8 +154,12 @@ struct PSink {   // value pass: lanes 0..17 -> column `lane` of M and of all foo
     }
 };
 struct DSink {   // tangent pass: d tau -> W[i][lane]; kinematic lanes (>=36) also store foot acc / vel tangents
-    WbDeriv* D; WbCore* C; int lane;
-    HD void base(const V3<Dual>&, const V3<Dual>&) const {}
+    WbDeriv* D; WbCore* C; int lane; int task;
+    HD void base(const V3<Dual>& f, const V3<Dual>& n) const {   // per-leg task of a base seed: partial base wrench, value and tangent (JPW is free during the pass)
+        double* p = D->JPW + 12 * task;
+        p[0] = f.x.v; p[1] = f.x.d; p[2] = f.y.v; p[3] = f.y.d; p[4] = f.z.v; p[5] = f.z.d;
+        p[6] = n.x.v; p[7] = n.x.d; p[8] = n.y.v; p[9] = n.y.d; p[10] = n.z.v; p[11] = n.z.d;
+    }
     HD void tau(int i, const Dual& v) const { D->W[i * WT + lane] = v.d; }
     HD void foot(int f, const V3<Dual>&, const V3<Dual>& v, const V3<Dual>& a) const {
         if (lane >= 36) {
@@ -334,15 +338,58 @@ template <int NT> HD void wb_keep_schur(WbCore& L, WbDeriv& D) {
     HS_PHASE(NT, for (int i = tid; i < 144; i += NT) D.LGs[i] = L.LG()[i]; if (tid < 12) D.rdGs[tid] = L.rdG[tid];)
 }
 
-// Tangent pass: lanes 0..35: d ID(q,v,acc)/dx_lane (psi_dyn, gravity `grav`); lanes 36..53: massless, foot forces L.fext,
-// psi_kin, tangent on q_(lane-36): tau tangent = -d(J^T F)/dq, foot acc / vel tangents.
+// Tangent pass.  SEEDS (the W column / foot-tangent column a result goes to): 0..35: d ID(q,v,acc)/dx_seed (psi_dyn, gravity `grav`);
+// 36..53: massless, foot forces L.fext, psi_kin, tangent on q_(seed-36): tau tangent = -d(J^T F)/dq, foot acc / vel tangents.
+// Run as 84 per-leg TASKS of about a quarter of a pass each, in two rounds of the wave:
+//   * a seed on a leg joint only moves its own leg: one task (other legs' rows / feet are zero, the base rows see this leg's wrench only);
+//   * a seed on a base rotation or a base velocity moves every leg: four tasks that leave their base wrench (value and tangent; the
+//     trunk's own inertial force rides with leg 0) as partial sums, added in leg order and walked back through the base joints afterwards;
+//   * a seed on the base position moves nothing that is stored (only foot positions depend on it): zeros.
 template <int NT>
 HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double vscale_dyn, double vscale_kin, double ascale_kin, bool q_only) {
-    HS_PHASE(NT, if (tid < 54 && !(q_only && tid >= 18 && tid < 36)) {
-        LaneCfg c = (tid < 36) ? lane_cfg(md, false, 1.0, grav, 0.0, vscale_dyn, 1.0, -1, tid < 18 ? tid : -1, tid >= 18 ? tid - 18 : -1)
-                               : lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, tid - 36, -1);
-        DSink sk{&D, &L, tid};
-        wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
+    // base seeds, q first so that q_only drops the tail: dyn q3..5 | kin q3..5 | dyn v0..5
+    auto base_seed = [](int bs) { return bs < 3 ? 3 + bs : bs < 6 ? 36 + bs : 12 + bs; };
+    HS_PHASE(NT,
+        _Pragma("unroll 1")
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int t = tid + 64 * rnd;
+            if (tid >= 64 || t >= 84) break;
+            int seed, leg; bool part = false;
+            if (t < 48) { seed = base_seed(t >> 2); leg = t & 3; part = true; if (q_only && t >= 24) continue; }
+            else { const int jl = (t - 48) % 12, grp = (t - 48) / 12; seed = (grp == 0 ? 6 : grp == 1 ? 42 : 24) + jl; leg = jl / 3; if (q_only && grp == 2) continue; }
+            LaneCfg c = (seed < 36) ? lane_cfg(md, false, 1.0, grav, 0.0, vscale_dyn, 1.0, -1, seed < 18 ? seed : -1, seed >= 18 ? seed - 18 : -1)
+                                    : lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, seed - 36, -1);
+            c.l0 = leg; c.l1 = leg + 1; c.body = part && leg == 0; c.partial = part;
+            DSink sk{&D, &L, seed, t};
+            wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
+            if (!part) {
+                for (int f = 0; f < 4; f++) if (f != leg) for (int r = 0; r < 3; r++) {
+                    D.W[(6 + 3 * f + r) * WT + seed] = 0.0;
+                    if (seed >= 36) { L.dacc()[(3 * f + r) * 18 + seed - 36] = 0.0; L.dvel()[(3 * f + r) * 18 + seed - 36] = 0.0; }
+                }
+            }
+        }
+        // base-position seeds (0..2 and 36..38): zero columns
+        for (int e = tid; e < 108; e += NT) { const int sd = e / 18, i = e % 18; D.W[i * WT + (sd < 3 ? sd : 33 + sd)] = 0.0; }
+        for (int e = tid; e < 36; e += NT) { const int j = e / 12, r = e % 12; L.dacc()[r * 18 + j] = 0.0; L.dvel()[r * 18 + j] = 0.0; })
+    HS_PHASE(NT, if (tid < (q_only ? 6 : 12)) {
+        const int seed = base_seed(tid), tq = seed < 18 ? seed : seed >= 36 ? seed - 36 : -1;
+        V3<Dual> fb = {Dual(0.0), Dual(0.0), Dual(0.0)}, nb = fb;
+        for (int l = 0; l < 4; l++) {
+            const double* p = D.JPW + 12 * (4 * tid + l);
+            fb = fb + V3<Dual>{Dual(p[0], p[1]), Dual(p[2], p[3]), Dual(p[4], p[5])}; nb = nb + V3<Dual>{Dual(p[6], p[7]), Dual(p[8], p[9]), Dual(p[10], p[11])};
+        }
+        auto SC = [&](int i, Dual& s_, Dual& c_) { const double c0 = L.cs[i], s0 = L.sn[i]; const bool sd = (tq == i); s_ = Dual(s0, sd ? c0 : 0.0); c_ = Dual(c0, sd ? -s0 : 0.0); };
+        Dual c3, s3, c4, s4, c5, s5;
+        SC(3, s3, c3); SC(4, s4, c4); SC(5, s5, c5);
+        DSink sk{&D, &L, seed, 0};
+        sk.tau(5, nb.x);
+        V3<Dual> f = rot<0>(c5, s5, fb), n = rot<0>(c5, s5, nb);
+        sk.tau(4, n.y);
+        f = rot<1>(c4, s4, f); n = rot<1>(c4, s4, n);
+        sk.tau(3, n.z);
+        f = rot<2>(c3, s3, f);
+        sk.tau(0, f.x); sk.tau(1, f.y); sk.tau(2, f.z);
     })
 }
 
