@@ -680,6 +680,8 @@ HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dve
     return g;
 }
 
+// cache commit: which regions a round of 64 elements (q) touches is known at compile time: no comparison chain per element
+#define KC_REGION(s_, e_, ptr_) if (64 * q + 63 >= (s_) && 64 * q < (e_)) { if (64 * q >= (s_) && 64 * q + 63 < (e_)) (ptr_)[i - (s_)] = v; else if (i >= (s_) && i < (e_)) (ptr_)[i - (s_)] = v; }
 // LQ approximation of knot k < h (recomputes the contact solve at the stored X,U like WBM.cpp:463)
 template <int NT>
 HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int reb_active, bool cached = false) {
@@ -713,17 +715,17 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
             if (c < P.ng) { D.bd()[c] = reb_active ? e * bd : 0.0; D.bdd()[c] = reb_active ? e * bdd : 0.0; }
         }
         if (cached) {
+            // trig table straight from the registers (same values wb_trig would read back from LDS), while the cache reads are in flight
+            if (tid < 18) { L.cs[tid] = cos(vx); L.sn[tid] = sin(vx); }
             _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) {
                 const int i = q * 64 + tid; const double v = r[q];
-                if (i < KC_X) L.M[i] = v; else if (i < KC_LG) L.Xm()[i - KC_X] = v; else if (i < KC_RDM) D.LGs[i - KC_LG] = v;
-                else if (i < KC_RDG) L.rdM[i - KC_RDM] = v; else if (i < KC_QDD) D.rdGs[i - KC_RDG] = v; else if (i < KC_GRF) L.qdd[i - KC_QDD] = v;
-                else if (i < KC_LAM) L.grf[i - KC_GRF] = v; else if (i < KC_J) L.lam[i - KC_LAM] = v; else if (i < KC_FP) L.Jall[i - KC_J] = v;
-                else if (i < KC_FV) L.fpos[i - KC_FP] = v; else if (i < KC_FV + 12) L.fvel[i - KC_FV] = v;
+                KC_REGION(KC_M, KC_X, L.M) KC_REGION(KC_X, KC_LG, L.Xm()) KC_REGION(KC_LG, KC_RDM, D.LGs) KC_REGION(KC_RDM, KC_RDG, L.rdM)
+                KC_REGION(KC_RDG, KC_QDD, D.rdGs) KC_REGION(KC_QDD, KC_GRF, L.qdd) KC_REGION(KC_GRF, KC_LAM, L.grf) KC_REGION(KC_LAM, KC_J, L.lam)
+                KC_REGION(KC_J, KC_FP, L.Jall) KC_REGION(KC_FP, KC_FV, L.fpos) KC_REGION(KC_FV, KC_FV + 12, L.fvel)
             }
         })
     LQ_STAMP(11)
     if (cached) {
-        wb_trig<NT>(L);
         LQ_STAMP(0)
     } else {
         HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
