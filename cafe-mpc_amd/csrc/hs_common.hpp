@@ -27,7 +27,7 @@
 // ~60 phase boundaries of a knot.  Larger workgroups keep the full barrier.
 template <int NT> __device__ __forceinline__ void hs_phase_sync() { __syncthreads(); }
 template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-#define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); if (tid < (NT)) { __VA_ARGS__ } } hs_phase_sync<(NT)>(); }
+#define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0); if (tid < (NT)) { __VA_ARGS__ } } hs_phase_sync<(NT)>(); }
 // wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program
 // order, so the only thing to prevent is compiler motion across the phase boundary.
 // LDS-only phase boundary: raw s_barrier behind an lgkmcnt(0) wait.  __syncthreads() carries a workgroup release fence,
@@ -35,7 +35,7 @@ template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("
 // prefetch loads that are meant to stay in flight across the knot.  Phases that only hand data over through LDS use this.
 // (tid is laundered through an empty asm so that index arithmetic derived from it is NOT hoisted out of the knot loop and
 // kept live in hundreds of registers / scratch slots)
-#define HS_PHASE_L(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); if (tid < (NT)) { __VA_ARGS__ } } asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#define HS_PHASE_L(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0); if (tid < (NT)) { __VA_ARGS__ } } asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 #define HS_WPHASE(...) { if (threadIdx.x < 64) { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 
