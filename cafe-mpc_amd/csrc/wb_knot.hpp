@@ -17,6 +17,7 @@
 #pragma once
 #include "hs_types.hpp"
 #include "wb_model.hpp"
+#include "hs_mfma.hpp"
 
 namespace hs {
 
@@ -680,6 +681,59 @@ HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dve
     return g;
 }
 
+// Foot-cost Hessian and gradient of a knot on the fp64 matrix cores (one wave).  With E the 24 x 36 matrix of cost rows
+//   rows 0..11  (position type, weight wp, residual ep): [0 0 0 | J(3f+r, 3:18) | 0]      (MHPCCost.cpp:54-59)
+//   rows 12..23 (velocity type, weight wv, residual ev): [d(foot vel)/dq | J(3f+r, :)]
+// the result is  E^T diag(w) [E | e]  (36 x 37): columns 0..35 -> W[row*36 + col] (dense staging tile of lxx), column 36 -> gvec.
+// 9 output tiles x 6 k-steps of v_mfma_f64_16x16x4; the three operand values of a k-step serve as A (scaled by the row weight) and
+// as B; a knot without velocity-type rows (all feet in stance, no touchdown) skips their three k-steps.
+template <int NT>
+HD void wb_cost_gram(WbLqLds& S, double* gvec) {
+    WbCore& L = S.c; WbDeriv& D = S.d;
+#ifdef HS_HOST_EMU
+    HS_PHASE_L(NT, if (tid < 37) {
+        const int j = tid;
+        auto E = [&](int k, int c) { if (k < 12) return (c >= 3 && c < 18) ? L.Jall[k * 18 + c] : 0.0; const int r = k - 12; return c < 18 ? L.dvel()[r * 18 + c] : L.Jall[r * 18 + c - 18]; };
+        for (int i = 0; i < 36; i++) {
+            double s = 0;
+            for (int k = 0; k < 24; k++) { const double w = k < 12 ? D.wp[k] : D.wv[k - 12]; s += w * E(k, i) * (j < 36 ? E(k, j) : (k < 12 ? D.ep[k] : D.ev[k - 12])); }
+            if (j < 36) D.W[i * 36 + j] = s; else gvec[i] = s;
+        }
+    })
+#else
+    HS_PHASE_L(NT, if (tid < 64) {
+        const int li = tid & 15, lk = tid >> 4;
+        bool anyv = false;
+        _Pragma("unroll") for (int a = 0; a < 12; a++) anyv = anyv || (D.wv[a] != 0.0);
+        d4_t c[3][3];
+        _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) c[ti][tj] = d4_t{0.0, 0.0, 0.0, 0.0};
+        _Pragma("unroll") for (int kg = 0; kg < 6; kg++) {
+            if (kg >= 3 && !anyv) break;
+            const int k = 4 * kg + lk, r = (kg < 3) ? k : k - 12;
+            const double w = (kg < 3) ? D.wp[r] : D.wv[r], res = (kg < 3) ? D.ep[r] : D.ev[r];
+            double e[3];
+            _Pragma("unroll") for (int t = 0; t < 3; t++) {
+                const int col = 16 * t + li, cc = col < 36 ? col : 35, lo = cc < 18, c18 = lo ? cc : cc - 18;
+                const double vj = L.Jall[r * 18 + c18];
+                if (kg < 3) e[t] = (cc >= 3 && lo && col < 36) ? vj : 0.0;
+                else { const double vd = L.dvel()[r * 18 + c18]; e[t] = col < 36 ? (lo ? vd : vj) : 0.0; }
+            }
+            _Pragma("unroll") for (int ti = 0; ti < 3; ti++) {
+                const double a = w * e[ti];
+                _Pragma("unroll") for (int tj = 0; tj < 3; tj++) {
+                    const double bb = (tj == 2 && li == 4) ? res : e[tj];      // column 36: the residual -> gradient
+                    c[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c[ti][tj], 0, 0, 0);
+                }
+            }
+        }
+        _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) _Pragma("unroll") for (int q = 0; q < 4; q++) {
+            const int row = 16 * ti + lk + 4 * q, col = 16 * tj + li;
+            if (row < 36) { if (col < 36) D.W[row * 36 + col] = c[ti][tj][q]; else if (col == 36) gvec[row] = c[ti][tj][q]; }
+        }
+    })
+#endif
+}
+
 // cache commit: which regions a round of 64 elements (q) touches is known at compile time: no comparison chain per element
 #define KC_REGION(s_, e_, ptr_) if (64 * q + 63 >= (s_) && 64 * q < (e_)) { if (64 * q >= (s_) && 64 * q + 63 < (e_)) (ptr_)[i - (s_)] = v; else if (i >= (s_) && i < (e_)) (ptr_)[i - (s_)] = v; }
 // LQ approximation of knot k < h (recomputes the contact solve at the stored X,U like WBM.cpp:463)
@@ -781,11 +835,12 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     LQ_STAMP(4)
     // ---------------- cost partials
     wb_cost_blocks<NT>(S, P, k, false);
+    wb_cost_gram<NT>(S, D.JPW);          // the column-solve staging has gone out to memory: JPW[0,36) takes the gradient
     HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
         double lxd = dt * P.q[d] * (L.x[d] - L.tmp[d]);
         double diag = dt * P.q[d];
-        lxd += wb_cost_column(D, L.Jall, L.dvel(), d, D.W + d);
+        lxd += D.JPW[d];
         // ReB fold on x (joint limits: x[6+i], height: x[2]) — rank-1 updates on the diagonal (ConstraintsBase.h:282-287)
         if (P.go_joint >= 0 && d >= 6 && d < 18) {
             const int i = d - 6;
