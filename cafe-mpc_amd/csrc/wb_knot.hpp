@@ -350,25 +350,35 @@ template <int NT>
 HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double vscale_dyn, double vscale_kin, double ascale_kin, bool q_only) {
     // base seeds, q first so that q_only drops the tail: dyn q3..5 | kin q3..5 | dyn v0..5
     auto base_seed = [](int bs) { return bs < 3 ? 3 + bs : bs < 6 ? 36 + bs : 12 + bs; };
+    // round A: the 60 DYNAMIC tasks (base q3..5 and v0..5 seeds x 4 legs, leg-joint q and v seeds); round B: the 24 KINEMATIC tasks
+    // (base q3..5 seeds x 4 legs, leg-joint q seeds) - each round runs an instruction stream without the other kind's dead work
+    auto zero_rest = [&](int seed, int leg) {
+        for (int f = 0; f < 4; f++) if (f != leg) for (int r = 0; r < 3; r++) {
+            D.W[(6 + 3 * f + r) * WT + seed] = 0.0;
+            if (seed >= 36) { L.dacc()[(3 * f + r) * 18 + seed - 36] = 0.0; L.dvel()[(3 * f + r) * 18 + seed - 36] = 0.0; }
+        }
+    };
     HS_PHASE(NT,
-        _Pragma("unroll 1")
-        for (int rnd = 0; rnd < 2; rnd++) {
-            const int t = tid + 64 * rnd;
-            if (tid >= 64 || t >= 84) break;
-            int seed, leg; bool part = false;
-            if (t < 48) { seed = base_seed(t >> 2); leg = t & 3; part = true; if (q_only && t >= 24) continue; }
-            else { const int jl = (t - 48) % 12, grp = (t - 48) / 12; seed = (grp == 0 ? 6 : grp == 1 ? 42 : 24) + jl; leg = jl / 3; if (q_only && grp == 2) continue; }
-            LaneCfg c = (seed < 36) ? lane_cfg(md, false, 1.0, grav, 0.0, vscale_dyn, 1.0, -1, seed < 18 ? seed : -1, seed >= 18 ? seed - 18 : -1)
-                                    : lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, seed - 36, -1);
+        if (tid < 60 && !(q_only && ((tid >= 12 && tid < 36) || tid >= 48))) {
+            const int t = tid; int seed, leg, slot = 0; bool part = t < 36;
+            if (t < 12) { seed = base_seed(t >> 2); leg = t & 3; slot = t; }
+            else if (t < 36) { const int bs = 6 + ((t - 12) >> 2); seed = base_seed(bs); leg = t & 3; slot = 4 * bs + leg; }
+            else { const int jl = (t - 36) % 12; seed = (t < 48 ? 6 : 24) + jl; leg = jl / 3; }
+            LaneCfg c = lane_cfg(md, false, 1.0, grav, 0.0, vscale_dyn, 1.0, -1, seed < 18 ? seed : -1, seed >= 18 ? seed - 18 : -1);
             c.l0 = leg; c.l1 = leg + 1; c.body = part && leg == 0; c.partial = part;
-            DSink sk{&D, &L, seed, t};
-            wb_pass<Dual>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
-            if (!part) {
-                for (int f = 0; f < 4; f++) if (f != leg) for (int r = 0; r < 3; r++) {
-                    D.W[(6 + 3 * f + r) * WT + seed] = 0.0;
-                    if (seed >= 36) { L.dacc()[(3 * f + r) * 18 + seed - 36] = 0.0; L.dvel()[(3 * f + r) * 18 + seed - 36] = 0.0; }
-                }
-            }
+            DSink sk{&D, &L, seed, slot};
+            wb_pass<Dual, DSink, 1>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
+            if (!part) zero_rest(seed, leg);
+        }
+        if (tid < 24) {
+            const int t = tid; int seed, leg, slot = 0; const bool part = t < 12;
+            if (part) { const int bs = 3 + (t >> 2); seed = base_seed(bs); leg = t & 3; slot = 4 * bs + leg; }
+            else { const int jl = t - 12; seed = 42 + jl; leg = jl / 3; }
+            LaneCfg c = lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, seed - 36, -1);
+            c.l0 = leg; c.l1 = leg + 1; c.body = false; c.partial = part;
+            DSink sk{&D, &L, seed, slot};
+            wb_pass<Dual, DSink, 2>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
+            if (!part) zero_rest(seed, leg);
         }
         // base-position seeds (0..2 and 36..38): zero columns
         for (int e = tid; e < 108; e += NT) { const int sd = e / 18, i = e % 18; D.W[i * WT + (sd < 3 ? sd : 33 + sd)] = 0.0; }

@@ -70,8 +70,12 @@ template <> HD Dual mkt<Dual>(double v, double t) { return Dual(v, t); }
 
 // One pass.  qs/vs/as: knot q(18), v(18), acceleration input(18); cs/sn: cos/sin of q (all LDS, broadcast reads);
 // fext: 12 world foot forces.
-template <class S, class SK>
+// MODE specialises the instruction stream of a whole round of lanes: 0 generic; 1 DYNAMIC (inertias on, no foot kinematics, no
+// external forces: what a d ID/dx task needs); 2 KINEMATIC (massless: no inertial forces, foot kinematics and external forces on).
+template <class S, class SK, int MODE = 0>
 HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const double* as, const double* cs, const double* sn, const double* fext, const SK& out) {
+    constexpr bool MASS = MODE != 2, FEET = MODE != 1;
+    const V3<S> zero3 = {S(0.0), S(0.0), S(0.0)};
     auto Q = [&](int i) { return mk<S>(qs[i], L.tq == i); };
     auto SC = [&](int i, S& s_, S& c_) { const double c0 = cs[i], s0 = sn[i]; const bool sd = (L.tq == i); s_ = mkt<S>(s0, sd ? c0 : 0.0); c_ = mkt<S>(c0, sd ? -s0 : 0.0); };
     auto Vv = [&](int i) { return mk<S>(L.vscale * vs[i], L.tv == i); };
@@ -87,7 +91,7 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
     rev_joint<1>(c4, s4, Vv(4), Aa(4), om, vl, aa, al);
     rev_joint<0>(c5, s5, Vv(5), Aa(5), om, vl, aa, al);
     V3<S> nb = {S(0.0), S(0.0), S(0.0)}, fb = nb;
-    if (L.body) inertia_force<S>(ms, 3.3, 0, 0, 0, 0.011253, 0, 0, 0.036203, 0, 0.042673, om, vl, al, aa, nb, fb);
+    if (MASS && L.body) inertia_force<S>(ms, 3.3, 0, 0, 0, 0.011253, 0, 0, 0.036203, 0, 0.042673, om, vl, al, aa, nb, fb);
     V3<S> ob = {Q(0), Q(1), Q(2)};
 #pragma unroll 1
     for (int l = L.l0; l < L.l1; l++) {
@@ -99,21 +103,22 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
         V3<S> o1 = om, a1 = aa;
         V3<S> v1 = vl + crossc(om, sx * 0.19, sy * 0.049, 0.0), l1 = al + crossc(aa, sx * 0.19, sy * 0.049, 0.0);
         rev_joint<0>(ca, sa, Vv(j0), Aa(j0), o1, v1, a1, l1);
-        V3<S> n1, f1;
-        inertia_force<S>(ms, 0.54, 0, sy * 0.036, 0, 0.000381, sy * 0.000058, 0.00000045, 0.000560, sy * 0.00000095, 0.000444, o1, v1, l1, a1, n1, f1);
+        V3<S> n1 = zero3, f1 = zero3;
+        if (MASS) inertia_force<S>(ms, 0.54, 0, sy * 0.036, 0, 0.000381, sy * 0.000058, 0.00000045, 0.000560, sy * 0.00000095, 0.000444, o1, v1, l1, a1, n1, f1);
         // hip: origin (0, sy*.062, 0) in abad, fixed yaw psi, axis y
         V3<S> o2 = o1, a2 = a1;
         V3<S> v2 = v1 + crossc(o1, 0.0, sy * 0.062, 0.0), l2 = l1 + crossc(a1, 0.0, sy * 0.062, 0.0);
         o2 = rotT<2>(L.cpsi, L.spsi, o2); v2 = rotT<2>(L.cpsi, L.spsi, v2); a2 = rotT<2>(L.cpsi, L.spsi, a2); l2 = rotT<2>(L.cpsi, L.spsi, l2);
         rev_joint<1>(ch, sh, Vv(j0 + 1), Aa(j0 + 1), o2, v2, a2, l2);
-        V3<S> n2, f2;
-        inertia_force<S>(ms, 0.634, 0, sy * 0.016, -0.02, 0.001983, sy * 0.000245, 0.000013, 0.002103, sy * 0.0000015, 0.000408, o2, v2, l2, a2, n2, f2);
+        V3<S> n2 = zero3, f2 = zero3;
+        if (MASS) inertia_force<S>(ms, 0.634, 0, sy * 0.016, -0.02, 0.001983, sy * 0.000245, 0.000013, 0.002103, sy * 0.0000015, 0.000408, o2, v2, l2, a2, n2, f2);
         // knee: origin (0,0,-.209) in thigh, axis y
         V3<S> o3 = o2, a3 = a2;
         V3<S> v3 = v2 + crossc(o2, 0.0, 0.0, -0.209), l3 = l2 + crossc(a2, 0.0, 0.0, -0.209);
         rev_joint<1>(ck, sk, Vv(j0 + 2), Aa(j0 + 2), o3, v3, a3, l3);
-        V3<S> n3, f3;
-        inertia_force<S>(ms, 0.064, 0, 0, -0.061, 0.000245, 0, 0, 0.000248, 0, 0.000006, o3, v3, l3, a3, n3, f3);
+        V3<S> n3 = zero3, f3 = zero3;
+        if (MASS) inertia_force<S>(ms, 0.064, 0, 0, -0.061, 0.000245, 0, 0, 0.000248, 0, 0.000006, o3, v3, l3, a3, n3, f3);
+        if (FEET) {
         // foot point r = (0,0,-.195) in shank
         V3<S> vp = v3 + crossc(o3, 0.0, 0.0, -0.195);
         V3<S> ap = l3 + crossc(a3, 0.0, 0.0, -0.195) + cross(o3, vp);
@@ -134,7 +139,8 @@ HD void wb_pass(const LaneCfg& L, const double* qs, const double* vs, const doub
             pw = ob + w;
         }
         out.foot(l, pw, vw, aw);
-        if (L.fscale != 0.0) {   // external world force at the foot -> shank coordinates, subtract
+        }
+        if (FEET && L.fscale != 0.0) {   // external world force at the foot -> shank coordinates, subtract
             V3<S> F = {S(L.fscale * fext[3 * l]), S(L.fscale * fext[3 * l + 1]), S(L.fscale * fext[3 * l + 2])};
             F = rotT<2>(c3, s3, F); F = rotT<1>(c4, s4, F); F = rotT<0>(c5, s5, F);
             F = rotT<0>(ca, sa, F); F = rotT<2>(L.cpsi, L.spsi, F); F = rotT<1>(ch, sh, F); F = rotT<1>(ck, sk, F);
