@@ -140,9 +140,9 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
 // ---- prefetch of one knot's record (backward sweep): RL::rounds rounds of 256 elements, each inside ONE sub-array,
 //      plus one round for the vectors [lx(N) lu(M) ly(PY) Defect[k+1](N)]
 #define SW_RICCATI_FETCH(kk_, k_) { \
-    const double* rec_ = P.rec + (kk_) * (size_t)RL::size + tid; \
+    const double* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
     _Pragma("unroll") for (int r = 0; r < RL::rounds; r++) PRE(r) = rec_[NT * r];     /* one base pointer, constant offsets */ \
-    PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
+    PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
 #define SW_RICCATI_COMMIT() { \
     constexpr int PYd = PY > 0 ? PY : 1; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } } \
@@ -203,10 +203,14 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
     const int h = P.h;
+    // trajectory pointers of the phase, read ONCE: a descriptor field fetched inside the knot loop is a vector load whose wait
+    // (vmcnt(0)) would also drain the record prefetch that is meant to stay in flight for a whole knot
+    const auto grec = P.rec; const auto gDefect = P.Defect; const auto gQu = P.Qu; const auto gQuu = P.Quu; const auto gQux = P.Qux;
+    const auto gK = P.K; const auto gdU = P.dU; const auto gG = P.G;
     SW_PRE_DECL
     // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327); prefetch knot h-1
     HS_PHASE(NT, { const int i = tid % N, j0 = tid / N; if (j0 < NT / N) for (int j = j0; j < N; j += NT / N) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * N * N + i + N * j]; }
-             if (tid < N) { const double g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; P.G[((size_t)b * (h + 1) + h) * N + tid] = g; }
+             if (tid < N) { const double g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; gG[((size_t)b * (h + 1) + h) * N + tid] = g; }
              if (tid == 0) { SWC.ok = 1; }
              SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1))
     for (int k = h - 1; k >= 0; k--) {
@@ -243,9 +247,9 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         })
         SW_STAMP(2)
         // regularisation on Quu; store Qu / Quu / Qux as the reference keeps them (callers read them)
-        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; P.Qu[kk * M + tid] = S.Qu[tid]; }
+        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; gQu[kk * M + tid] = S.Qu[tid]; }
                    else if (tid >= 64 && tid < 64 + N) CM(S.Qxx, tid - 64, tid - 64, LDN) += reg;)     // regularisation on Qxx as well: quirk x
-        HS_PHASE_L(NT, st_mat<NT>(tid, P.Quu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, P.Qux + kk * M * N, S.Qux, LDM, M, N);)
+        HS_PHASE_L(NT, st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
         chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &SWC.ok);
@@ -274,17 +278,17 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
               for (int tile = w; tile < TN * TN; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % TN), 16 * (tile / TN), N, N, S.Qux, LDM, S.K, LDM); }
-            if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; P.G[((size_t)b * (h + 1) + k) * N + i] = s; }
+            if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
             else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
-            else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); P.dU[kk * M + a] = S.dU[a]; })
+            else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); gdU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
-        HS_PHASE_L(NT, st_mat<NT>(tid, P.K + kk * M * N, S.K, LDM, M, N);)
+        HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N);)
         SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
-    HS_PHASE(NT, if (tid < N) S.def[tid] = P.Defect[((size_t)b * (h + 1)) * N + tid];)
+    HS_PHASE(NT, if (tid < N) S.def[tid] = gDefect[((size_t)b * (h + 1)) * N + tid];)
     HS_PHASE(NT, if (tid < N) { double s = S.G[tid]; for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
-    HS_PHASE(NT, if (tid < N) { SWC.xfer[tid] = S.Gn[tid]; P.G[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
+    HS_PHASE(NT, if (tid < N) { SWC.xfer[tid] = S.Gn[tid]; gG[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
              st_mat<NT>(tid, P.H0 + (size_t)b * N * N, S.H, LDN, N, N);)
     return true;
 }
@@ -330,12 +334,12 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
 // ---- linear rollout: forward over phases/knots; next knot prefetched into registers (dense ld = rows layouts) ----
 //   rounds: A (rA) | lxx (rA) | B (rB) | K (rB) | luu (rLuu) | [lx(N) lu(M) dU(M) Defect[k+1](N)]
 #define SW_LIN_FETCH(kk_, k_) { \
-    const double* rec_ = P.rec + (kk_) * (size_t)RL::size + tid; \
+    const double* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { PRE(r) = rec_[RL::oA + NT * r]; PRE(RL::rA + r) = rec_[RL::oLxx + NT * r]; } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? P.K[(kk_) * M * N + e] : 0.0; } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? gK[(kk_) * M * N + e] : 0.0; } \
     _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(2 * RL::rA + 2 * RL::rB + r) = rec_[RL::oLuu + NT * r]; \
-    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? P.dU[(kk_) * M + tid - N - M] \
-            : (tid < 2 * N + 2 * M) ? P.Defect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
+    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? gdU[(kk_) * M + tid - N - M] \
+            : (tid < 2 * N + 2 * M) ? gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
 #define SW_LIN_COMMIT(p_) { \
     double* A_ = (p_) ? S.H : S.A; double* Q_ = (p_) ? S.HA : S.Qxx; double* B_ = (p_) ? S.HB : S.B; double* K_ = (p_) ? S.Qux : S.K; double* U_ = (p_) ? S.LQ : S.Quu; \
     double* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
@@ -357,6 +361,7 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
     static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(double), "the partial-sum scratch must not reach dx");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
+    const auto grec = P.rec; const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX;   // read once (see riccati_phase)
     SW_PRE_DECL
 #ifdef HS_HOST_EMU
     static double acc1_all_[NT], acc2_all_[NT];
@@ -369,7 +374,7 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
 #define ACC2 acc2_
 #endif
     // dX[0] = dx_init + eps * Defect[0]
-    HS_PHASE(NT, if (tid < N) { double v = SWC.xfer[tid] + eps * P.Defect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; P.dX[((size_t)b * (h + 1)) * N + tid] = v; }
+    HS_PHASE(NT, if (tid < N) { double v = SWC.xfer[tid] + eps * gDefect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; gdX[((size_t)b * (h + 1)) * N + tid] = v; }
              SW_LIN_FETCH((size_t)b * h, 0))
     HS_PHASE_L(NT, SW_LIN_COMMIT(0) if (1 < h) SW_LIN_FETCH((size_t)b * h + 1, 1))
     for (int k = 0; k < h; k++) {
@@ -386,7 +391,7 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
                 double s2 = 0;
                 _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(B_, tid, j, N) * S.du[j];
                 const double v = s + s2 + eps * def_[tid];
-                dxw[tid] = v; P.dX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
+                dxw[tid] = v; gdX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
                 ACC2 += dxc[tid] * q;             // dx^T lxx dx
                 ACC1 += Qx_[tid] * dxc[tid];
             } else if (tid >= 128 && tid < 128 + M) {
