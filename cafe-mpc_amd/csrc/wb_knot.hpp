@@ -427,6 +427,24 @@ HD double wb_constraint(PhaseC& P, const WbCore& L, int c) {
 
 struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // per (problem, slot) partials
 
+// Copy-out of a CNT-element image whose element e = r + ROWS*c is produced by f(e, r, c) (LDS reads / constants): fully unrolled, every
+// read is issued before the first store, (r, c) follow e = tid + NT*q without a division.  One wave; no barrier inside.
+template <int NT, int CNT, int ROWS, class DST, class F>
+HD void store_image(DST dst, int tid, F f) {
+    constexpr int R = (CNT + NT - 1) / NT;
+    const int c0 = tid / ROWS, r0 = tid - ROWS * c0;
+    double v[R];
+    _Pragma("unroll")
+    for (int q = 0; q < R; q++) {
+        const int e = tid + NT * q; int r = r0 + (NT * q) % ROWS, c = c0 + (NT * q) / ROWS;
+        if (r >= ROWS) { r -= ROWS; c++; }
+        v[q] = 0.0;
+        if (R * NT == CNT || e < CNT) v[q] = f(e, r, c);
+    }
+    _Pragma("unroll")
+    for (int q = 0; q < R; q++) { const int e = tid + NT * q; if (R * NT == CNT || e < CNT) dst[e] = v[q]; }
+}
+
 // -------------------------------------------------------------------------------------------------------
 // Rollout of one knot k < h of problem b.   eps: line-search step.
 template <int NT>
@@ -472,9 +490,10 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
         double* kc = P.kc + kk * KC_SIZE;
         HS_PHASE_L(NT,
-            for (int i = tid; i < 324; i += NT) kc[KC_M + i] = L.M[i];
-            for (int i = tid; i < 216; i += NT) { kc[KC_X + i] = L.Xm()[i]; kc[KC_J + i] = L.Jall[i]; }
-            for (int i = tid; i < 144; i += NT) kc[KC_LG + i] = L.LG()[i];
+            store_image<NT, 324, 324>(kc + KC_M, tid, [&](int e, int, int) { return L.M[e]; });
+            store_image<NT, 216, 216>(kc + KC_X, tid, [&](int e, int, int) { return L.Xm()[e]; });
+            store_image<NT, 216, 216>(kc + KC_J, tid, [&](int e, int, int) { return L.Jall[e]; });
+            store_image<NT, 144, 144>(kc + KC_LG, tid, [&](int e, int, int) { return L.LG()[e]; });
             if (tid < 18) { kc[KC_RDM + tid] = L.rdM[tid]; kc[KC_QDD + tid] = L.qdd[tid]; }
             if (tid < 12) { kc[KC_RDG + tid] = L.rdG[tid]; kc[KC_GRF + tid] = L.grf[tid]; kc[KC_LAM + tid] = L.lam[tid]; kc[KC_FP + tid] = L.fpos[tid]; kc[KC_FV + tid] = L.fvel[tid]; })
     }
@@ -508,10 +527,12 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         }
         S[48 + f] = l2; S[52 + f] = l3; S[56 + f] = l4;
     }
+    double gmin = 0.0;     // this lane's share of min(0, min_c g_c); the 64 partial minima are folded by one lane below (a minimum does not depend on the order)
     for (int c = tid; c < P.ng; c += NT) {
         const double g = wb_constraint(P, L, c), e = L.gval()[c], dl = L.bar()[c];
-        P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl);
-    })
+        P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl); gmin = fmin(gmin, g);
+    }
+    if (tid < 64) S[200 + tid] = gmin;)
     RL_STAMP(4)
     HS_PHASE(NT, if (tid == 0) {          // running cost in the reference's order of additions
         double lq = 0, lr = 0;
@@ -524,10 +545,13 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         P.lbase[kk] = l; S[140] = l;
     } else if (tid >= 8 && tid < 13) {    // ReB_cost of constraint object tid-8 (SinglePhase.cpp:394-402)
         int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); const int gI = tid - 8;
-        double c = 0; if (gI < nobj) for (int i = 0; i < sz[gI]; i++) c += L.bar()[offs[gI] + i];
+        // same order of additions as before, but a fixed trip count (an object has at most 24 constraints): the LDS reads are batched
+        // instead of one exposed round trip per term
+        double c = 0; const int n_ = gI < nobj ? sz[gI] : 0, o_ = gI < nobj ? offs[gI] : 0;
+        _Pragma("unroll") for (int i = 0; i < 24; i++) { const double v = L.bar()[o_ + (i < n_ ? i : 0)]; if (i < n_) c += v; }
         S[141 + gI] = c;
     } else if (tid == 16) {
-        double ming = 0; for (int c = 0; c < P.ng; c++) ming = fmin(ming, L.gval()[c]);
+        double ming = 0; _Pragma("unroll") for (int c = 0; c < 64; c++) ming = fmin(ming, S[200 + c]);
         so.ming[slot] = ming; so.maxh[slot] = 0.0;
     } else if (tid == 32) {
         double dsq = 0; for (int i = 0; i < 36; i++) dsq += S[64 + i];
@@ -604,23 +628,6 @@ HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md
 // -------------------------------------------------------------------------------------------------------
 // coalesced copy LDS -> global
 template <int NT> HD void store_block(double* dst, const double* src, int n) { HS_PHASE_L(NT, for (int i = tid; i < n; i += NT) dst[i] = src[i];) }
-// Copy-out of a CNT-element image whose element e = r + ROWS*c is produced by f(e, r, c) (LDS reads / constants): fully unrolled, every
-// read is issued before the first store, (r, c) follow e = tid + NT*q without a division.  One wave; no barrier inside.
-template <int NT, int CNT, int ROWS, class DST, class F>
-HD void store_image(DST dst, int tid, F f) {
-    constexpr int R = (CNT + NT - 1) / NT;
-    const int c0 = tid / ROWS, r0 = tid - ROWS * c0;
-    double v[R];
-    _Pragma("unroll")
-    for (int q = 0; q < R; q++) {
-        const int e = tid + NT * q; int r = r0 + (NT * q) % ROWS, c = c0 + (NT * q) / ROWS;
-        if (r >= ROWS) { r -= ROWS; c++; }
-        v[q] = 0.0;
-        if (R * NT == CNT || e < CNT) v[q] = f(e, r, c);
-    }
-    _Pragma("unroll")
-    for (int q = 0; q < R; q++) { const int e = tid + NT * q; if (R * NT == CNT || e < CNT) dst[e] = v[q]; }
-}
 
 // References of knot k for the cost partials, fetched with the state so that no later phase waits on HBM:
 //   tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
