@@ -108,6 +108,29 @@ HD void mfma_tile(int lane, double* Cout, int ldc, const double* Cin, int ldcin,
 #endif
 }
 
+// Sum over the 4 lanes of an aligned quad in the order (p0 + p1) + (p2 + p3), by two DPP quad permutes (no LDS traffic); every
+// lane of the quad receives the sum.  The linear rollout is a chain of mat-vec products: splitting each row over a quad cuts the
+// dependent multiply-add chain of a knot by four.
+#ifndef HS_HOST_EMU
+template <int CTRL> HD double dpp_quad(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+HD double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }     // quad_perm [1,0,3,2], then [2,3,0,1]
+#endif
+// SW_QUAD_ROWS(CNT, PARTIAL, FINISH): for each output o < CNT, PARTIAL computes `partial` and `partial2` from (o, part = 0..3), FINISH
+// consumes `total` / `total2` = (p0 + p1) + (p2 + p3).  GPU: the four lanes of quad o (tid = 4 o + part), FINISH on the part-0 lane;
+// emulator: thread o does all four parts itself.  SW_QS: lane stride between the lanes that run FINISH.
+#ifdef HS_HOST_EMU
+#define SW_QS 1
+#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if (tid < (CNT)) { const int o = tid; double p_[4]; double p2_[4]; for (int part = 0; part < 4; part++) { double partial = 0; double partial2 = 0; PARTIAL p_[part] = partial; p2_[part] = partial2; } \
+    const double total = (p_[0] + p_[1]) + (p_[2] + p_[3]); const double total2 = (p2_[0] + p2_[1]) + (p2_[2] + p2_[3]); (void)total2; FINISH }
+#else
+#define SW_QS 4
+#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if ((tid >> 2) < (CNT)) { const int o = tid >> 2; const int part = tid & 3; double partial = 0; double partial2 = 0; PARTIAL \
+    const double total = quad_sum(partial); const double total2 = quad_sum(partial2); (void)total2; if (part == 0) FINISH }
+#endif
+
 // ---- wave-level (wave 0) factorisation helpers, compile-time size, recurrences in registers -------------------
 template <int N, int LD>
 HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok) {
@@ -357,7 +380,7 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
 template <int NT, int N, int M, int PY>
 HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
-    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && N <= 64 && M <= 64, "prefetch registers / lane maps");
+    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT, "prefetch registers / lane maps");
     static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(double), "the partial-sum scratch must not reach dx");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
@@ -383,19 +406,24 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
         const double* A_ = p ? S.H : S.A; const double* Q_ = p ? S.HA : S.Qxx; const double* B_ = p ? S.HB : S.B; const double* K_ = p ? S.Qux : S.K; const double* U_ = p ? S.LQ : S.Quu;
         const double* Qx_ = p ? S.red : S.Qx; const double* Qu_ = p ? S.red + 64 : S.Qu; const double* dU_ = p ? S.red + 128 : S.dU; const double* def_ = p ? S.red + 192 : S.def;
         const double* dxc = p ? S.dxn : S.dx; double* dxw = p ? S.dx : S.dxn;
-        HS_PHASE_L(NT, if (tid < M) { double s = eps * dU_[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(K_, tid, j, M) * dxc[j]; S.du[tid] = s; })
+        // du = eps dU + K dx : row o by the four lanes of quad o
+        HS_PHASE_L(NT, SW_QUAD_ROWS(M, {
+            constexpr int CH = (N + 3) / 4; double s = 0;
+            _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int j = part * CH + jj; if (j < N) s += CM(K_, o, j, M) * dxc[j]; }
+            partial = s; }, { S.du[o] = eps * dU_[o] + total; }))
         HS_PHASE_L(NT,
-            if (tid < N) {
-                double s = 0, q = 0;
-                _Pragma("unroll 6") for (int j = 0; j < N; j++) { s += CM(A_, tid, j, N) * dxc[j]; q += CM(Q_, tid, j, N) * dxc[j]; }
-                double s2 = 0;
-                _Pragma("unroll") for (int j = 0; j < M; j++) s2 += CM(B_, tid, j, N) * S.du[j];
-                const double v = s + s2 + eps * def_[tid];
-                dxw[tid] = v; gdX[((size_t)b * (h + 1) + k + 1) * N + tid] = v;
-                ACC2 += dxc[tid] * q;             // dx^T lxx dx
-                ACC1 += Qx_[tid] * dxc[tid];
-            } else if (tid >= 128 && tid < 128 + M) {
-                const int a = tid - 128; double q = 0;
+            // dx+ = [A B] [dx; du] + eps defect and q = lxx dx : row o by quad o, a quarter of the N + M (resp. N) terms per lane
+            SW_QUAD_ROWS(N, {
+                constexpr int T = N + M; constexpr int CH = (T + 3) / 4; constexpr int CQ = (N + 3) / 4; double s = 0; double q = 0;
+                _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int t = part * CH + jj; if (t < N) s += CM(A_, o, t, N) * dxc[t]; else if (t < T) s += CM(B_, o, t - N, N) * S.du[t - N]; }
+                _Pragma("unroll") for (int jj = 0; jj < CQ; jj++) { const int j = part * CQ + jj; if (j < N) q += CM(Q_, o, j, N) * dxc[j]; }
+                partial = s; partial2 = q; }, {
+                const double v = total + eps * def_[o];
+                dxw[o] = v; gdX[((size_t)b * (h + 1) + k + 1) * N + o] = v;
+                ACC2 += dxc[o] * total2;          // dx^T lxx dx
+                ACC1 += Qx_[o] * dxc[o]; })
+            if (tid >= 192 && tid < 192 + M) {
+                const int a = tid - 192; double q = 0;
                 _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(U_, a, j, M) * S.du[j];
                 ACC2 += S.du[a] * q; ACC1 += Qu_[a] * S.du[a];      // (+ du^T lux dx with lux == 0)
             }
@@ -404,11 +432,12 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
     const double* dxe = (h & 1) ? S.dxn : S.dx;
     // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx ; then the per-lane partial sums of the whole phase
     HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
-    HS_PHASE(NT, if (tid < N) { double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, tid, j, N) * dxe[j]; ACC2 += dxe[tid] * q; ACC1 += P.Phix[(size_t)b * N + tid] * dxe[tid]; })
+    HS_PHASE(NT, if (tid % SW_QS == 0 && tid / SW_QS < N) { const int o = tid / SW_QS;      // on the lanes that carry the x-part partial sums
+                     double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, o, j, N) * dxe[j]; ACC2 += dxe[o] * q; ACC1 += P.Phix[(size_t)b * N + o] * dxe[o]; })
     double* scr = SS.raw;     // 2 x NT partial sums (the matrices are no longer needed; dx / dxn live beyond the first 2 NT doubles of every view)
     HS_PHASE(NT, scr[tid] = ACC1; scr[NT + tid] = ACC2;)
-    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[j]; a2 += scr[NT + j]; }
-                                 double b1 = 0, b2 = 0; for (int j = 0; j < M; j++) { b1 += scr[128 + j]; b2 += scr[NT + 128 + j]; }
+    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[SW_QS * j]; a2 += scr[NT + SW_QS * j]; }
+                                 double b1 = 0, b2 = 0; for (int j = 0; j < M; j++) { b1 += scr[192 + j]; b2 += scr[NT + 192 + j]; }
                                  SWC.dV1 += a1 + b1; SWC.dV2 += a2; SWC.dV2 += b2; }
              if (tid >= 64 && tid < 64 + N) SWC.xfer[tid - 64] = dxe[tid - 64];)
 #undef ACC1
