@@ -820,10 +820,11 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) {
             bot[a] = 0.0;
-            if (a < m && d < 36) {
-                const int r = 3 * P.feet[a / 3] + a % 3;
-                if (d < 18) bot[a] = L.G()[r * 18 + d] + 2.0 * P.bg_alpha * L.dvel()[r * 18 + d];
-                else bot[a] = 2.0 * L.dvel()[r * 18 + (d - 18)] + 2.0 * P.bg_alpha * L.Jall[r * 18 + (d - 18)];   // footAccPartialDv == 2 footVelPartialDq
+            if (a < m) {      // uniform over the wave; the q / v halves differ only in which arrays feed the two terms: selects, no divergent branches
+                const int r = 3 * P.feet[a / 3] + a % 3, dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18;
+                const double vg = L.G()[r * 18 + c], vd = L.dvel()[r * 18 + c], vj = L.Jall[r * 18 + c];
+                const double t1 = dc < 18 ? vg : 2.0 * vd, t2 = dc < 18 ? vd : vj;       // footAccPartialDv == 2 footVelPartialDq
+                bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
             }
         }
         wb_kkt_column(L, D, top, bot, false);
