@@ -37,6 +37,7 @@ struct WbCore {
     HD double* dacc() { return GG; }          // LQ program: [3f+r][18] tangents of the foot accelerations
     HD double* dvel() { return GG + 216; }    // LQ program: [3f+r][18] tangents of the foot velocities (= footVelPartialDq)
     double a0[18], rhs[12], lam[12], qdd[18], grf[12], tmp[64], red[64], rdM[18], rdG[12];
+    double wq[48];                     // running-cost weights q (36) | r (12) of the phase, fetched with the knot's other global reads
     double xnext[36];                  // single-shooting chain: the state handed from one knot to the next inside the wave
     unsigned long long tstamp;
 };
@@ -212,10 +213,16 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
     })
 }
 
+// A per-lane index into a small descriptor array would be a VECTOR load from the descriptor in the middle of a knot (an exposed
+// round trip for the single wave); the elements are fetched as scalars instead and picked by selects.
+struct Feet4 { int f0, f1, f2, f3; HD int operator[](int i) const { return i == 0 ? f0 : i == 1 ? f1 : i == 2 ? f2 : f3; } };
+HD Feet4 feet_of(PhaseC& P) { return Feet4{P.feet[0], P.feet[1], P.feet[2], P.feet[3]}; }
+template <class T> HD double pick3(const T& w, int a) { const double w0 = w[0], w1 = w[1], w2 = w[2]; return a == 0 ? w0 : a == 1 ? w1 : w2; }
+
 // compact active Jacobian + drift, PADDED to 12 rows (rows >= 3*nc are zero) so that every later loop has a
 // compile-time trip count (mode 0: gam = Jdot v + 2 alpha J v ; mode 1: 0)
 template <int NT>
-HD void wb_select(WbCore& L, int nc, const int* feet, int mode, double alpha) {
+HD void wb_select(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) {
     HS_PHASE(NT,
         for (int e = tid; e < 216; e += NT) {
             const int a = e / 18, j = e % 18; const bool act = a < 3 * nc;
@@ -243,7 +250,7 @@ HD void wb_gram(WbCore& L, int m, int tid, int nt) {
 //   mode 0 (Pinocchio forwardDynamics): y = L^-1 (tau - h), lam = G^-1 (-X^T y - gam), qdd = L^-T (y + X lam)
 //   mode 1 (Pinocchio impulseDynamics): lam = G^-1 (-Jc v), v+ = v + L^-T X lam
 template <int NT>
-HD void wb_kkt_direct(WbCore& L, int nc, const int* feet, int mode, double alpha) {
+HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) {
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
     LQ_STAMP(7)
@@ -414,9 +421,9 @@ HD double reb_barrier(double g, double delta) {   // ConstraintsBase.h:238-245
 HD double wb_constraint(PhaseC& P, const WbCore& L, int c) {
     if (P.go_torque >= 0 && c >= P.go_torque && c < P.go_torque + 24) { int i = c - P.go_torque; return i < 12 ? -L.u[i] + P.torque_limit : L.u[i - 12] + P.torque_limit; }
     if (P.go_jspeed >= 0 && c >= P.go_jspeed && c < P.go_jspeed + 24) { int i = c - P.go_jspeed; return i < 12 ? L.x[24 + i] - P.jspeed_lb : -L.x[24 + i - 12] + P.jspeed_ub; }
-    if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) { int i = c - P.go_joint; return i < 12 ? L.x[6 + i] - P.joint_lb[i % 3] : -L.x[6 + i - 12] + P.joint_ub[i % 3]; }
+    if (P.go_joint >= 0 && c >= P.go_joint && c < P.go_joint + 24) { int i = c - P.go_joint; return i < 12 ? L.x[6 + i] - pick3(P.joint_lb, i % 3) : -L.x[6 + i - 12] + pick3(P.joint_ub, i % 3); }
     if (P.go_height >= 0 && c == P.go_height) return L.x[2] - P.h_min;
-    int i = c - P.go_grf, a = i / 5, r = i % 5, f = P.feet[a];
+    int i = c - P.go_grf, a = i / 5, r = i % 5, f = feet_of(P)[a];
     double fx = L.grf[3 * f], fy = L.grf[3 * f + 1], fz = L.grf[3 * f + 2];
     if (r == 0) return fz;
     if (r == 1) return -fx + P.mu * fz;
@@ -464,6 +471,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         if (tid < 36) { va = P.Xbar[kx + tid]; vb = P.dX[kx + tid]; vc = P.xr[(size_t)k * 36 + tid]; if (!ss) { vd = P.Xbar[kx + 36 + tid]; ve = P.dX[kx + 36 + tid]; } }
         else if (tid < 48) { const int i = tid - 36; vc = P.ur[(size_t)k * 12 + i]; vd = P.Ubar[ku + i]; ve = P.dU[ku + i]; }
         else if (tid < 60) vc = P.foot_vel[(size_t)k * 12 + tid - 48];
+        const double vw = (tid < 36) ? P.q[tid] : (tid < 48) ? P.r[tid - 36] : 0.0;
         double kr[7], er[2], dr[2];
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
@@ -474,7 +482,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
             L.tmp[tid] = vc; L.red[tid] = ss ? 0.0 : vd + eps * ve;
         } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
         else if (tid < 60) L.tmp[tid] = vc;
-        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;
+        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = kr[q]; }
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
     HS_PHASE(NT, if (tid < 12) {
@@ -485,7 +493,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     RL_STAMP(0)
     wb_terms<NT>(L, md, true);
     RL_STAMP(1)
-    wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
+    wb_kkt_direct<NT>(L, P.nc, feet_of(P), 0, P.bg_alpha);
     RL_STAMP(2)
     {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
         double* kc = P.kc + kk * KC_SIZE;
@@ -510,10 +518,10 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         double dsq = d * d;
         if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
         S[64 + tid] = dsq; S[100 + tid] = xs * xs;
-        const double dx = L.x[tid] - L.tmp[tid]; S[tid] = dx * P.q[tid] * dx;
+        const double dx = L.x[tid] - L.tmp[tid]; S[tid] = dx * L.wq[tid] * dx;
     } else if (tid < 48) {
         const int i = tid - 36; P.Y[kk * 12 + i] = L.grf[i];
-        const double du = L.u[i] - L.tmp[tid]; S[tid] = du * P.r[i] * du;
+        const double du = L.u[i] - L.tmp[tid]; S[tid] = du * L.wq[36 + i] * du;
     } else if (tid < 52) {     // foot costs of foot f: place regulariser (stance), swing position, swing velocity (MHPCCost.cpp:4-245)
         const int f = tid - 48; const int rc = P.ref_contact[(size_t)k * 4 + f];
         const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
@@ -608,8 +616,8 @@ HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md
     if (Pn == nullptr) return;
     // reset map (MHPCReset.cpp:4-28): impact if any touchdown, then optional WB->SRB projection
     if (impact) {
-        int tdfeet[4]; int ntd = 0; for (int f = 0; f < 4; f++) if (P.td[f]) tdfeet[ntd++] = f;
-        wb_kkt_direct<NT>(L, ntd, tdfeet, 1, 0.0);
+        int tdfeet[4] = {0, 0, 0, 0}; int ntd = 0; for (int f = 0; f < 4; f++) if (P.td[f]) tdfeet[ntd++] = f;
+        wb_kkt_direct<NT>(L, ntd, Feet4{tdfeet[0], tdfeet[1], tdfeet[2], tdfeet[3]}, 1, 0.0);
     } else { HS_PHASE(NT, if (tid < 18) L.qdd[tid] = L.x[18 + tid];) }
     const int nn = Pn->n;
     const size_t nx = ((size_t)b * (Pn->h + 1)) * nn;
@@ -651,11 +659,11 @@ HD void wb_cost_blocks(WbLqLds& S, PhaseC& P, int k, bool terminal) {
             const int f = tid / 3, a = tid % 3;
             double wpos = 0, wvel = 0;
             if (!terminal) {
-                if (rc[f] > 0 && P.w_foot_reg[0] >= 0) wpos = P.w_foot_reg[a] * P.dt;
-                if (rc[f] == 0 && P.w_swing_pos[0] >= 0) wpos = P.w_swing_pos[a] * P.dt;
-                if (rc[f] == 0 && P.w_swing_vel[0] >= 0) wvel = P.w_swing_vel[a] * P.dt;
+                if (rc[f] > 0 && P.w_foot_reg[0] >= 0) wpos = pick3(P.w_foot_reg, a) * P.dt;
+                if (rc[f] == 0 && P.w_swing_pos[0] >= 0) wpos = pick3(P.w_swing_pos, a) * P.dt;
+                if (rc[f] == 0 && P.w_swing_vel[0] >= 0) wvel = pick3(P.w_swing_vel, a) * P.dt;
             } else {
-                if (rc[f] > 0 && P.w_foot_reg[0] >= 0) wpos = 2.0 * P.w_foot_reg[a];
+                if (rc[f] > 0 && P.w_foot_reg[0] >= 0) wpos = 2.0 * pick3(P.w_foot_reg, a);
                 if (P.td[f] && P.n_td > 0 && P.w_td_vel >= 0 && a == 2) wvel = P.w_td_vel;
             }
             D.wp[tid] = wpos; D.wv[tid] = wvel;
@@ -767,6 +775,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         const double vt = (tid < 36) ? P.xr[(size_t)k * 36 + tid] : (tid < 48) ? P.ur[(size_t)k * 12 + tid - 36] : 0.0;
         const double vf = (tid < 12) ? P.foot_pos[(size_t)k * 12 + tid] : (tid < 15) ? P.body_pos[(size_t)k * 3 + tid - 12] : (tid < 19) ? (double)P.ref_contact[(size_t)k * 4 + tid - 15] : 0.0;
         const double vv = (tid < 12) ? P.foot_vel[(size_t)k * 12 + tid] : 0.0;
+        const double vw = (tid < 36) ? P.q[tid] : (tid < 48) ? P.r[tid - 36] : 0.0;
         double gr[2], dr[2], er[2];
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; const size_t gi = kk * P.ng + c; const bool in = c < P.ng; gr[q] = in ? P.g[gi] : 1.0; dr[q] = in ? P.delta[gi] : 1.0; er[q] = in ? P.eps[gi] : 0.0; }
         double r[KC_SIZE / 64];
@@ -778,7 +787,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         if (tid < 36) L.x[tid] = vx; if (tid < 12) { L.u[tid] = vu; L.fext[tid] = 0.0; }
         if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; }
         // cost references (layout of wb_cost_prefetch): tmp[0,36) xr | tmp[36,48) ur | red[0,12) foot_pos | red[12,24) foot_vel | red[24,27) body_pos | red[28,32) ref_contact
-        if (tid < 48) L.tmp[tid] = vt;
+        if (tid < 48) { L.tmp[tid] = vt; L.wq[tid] = vw; }
         if (tid < 12) { L.red[tid] = vf; L.red[12 + tid] = vv; } else if (tid < 15) L.red[12 + tid] = vf; else if (tid < 19) L.red[13 + tid] = vf;
         _Pragma("unroll") for (int q = 0; q < 2; q++) {
             const int c = q * NT + tid; const double g = gr[q], delta = dr[q], e = er[q]; double bd, bdd;
@@ -802,7 +811,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
         wb_terms<NT>(L, md, true);
         LQ_STAMP(0)
-        wb_kkt_direct<NT>(L, P.nc, P.feet, 0, P.bg_alpha);
+        wb_kkt_direct<NT>(L, P.nc, feet_of(P), 0, P.bg_alpha);
         wb_keep_schur<NT>(L, D);
     }
     LQ_STAMP(1)
@@ -856,8 +865,8 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     wb_cost_gram<NT>(S, D.JPW);          // the column-solve staging has gone out to memory: JPW[0,36) takes the gradient
     HS_PHASE_L(NT, if (tid < 36) {
         const int d = tid;
-        double lxd = dt * P.q[d] * (L.x[d] - L.tmp[d]);
-        double diag = dt * P.q[d];
+        double lxd = dt * L.wq[d] * (L.x[d] - L.tmp[d]);
+        double diag = dt * L.wq[d];
         lxd += D.JPW[d];
         // ReB fold on x (joint limits: x[6+i], height: x[2]) — rank-1 updates on the diagonal (ConstraintsBase.h:282-287)
         if (P.go_joint >= 0 && d >= 6 && d < 18) {
@@ -878,7 +887,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     HS_PHASE_L(NT, for (int i = tid; i < 288; i += NT) L.Jc()[i] = 0.0;)
     HS_PHASE_L(NT, if (tid < 12) {
         const int i = tid;
-        double lu = dt * P.r[i] * (L.u[i] - L.tmp[36 + i]), luu = dt * P.r[i];
+        double lu = dt * L.wq[36 + i] * (L.u[i] - L.tmp[36 + i]), luu = dt * L.wq[36 + i];
         if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }
         P.lu[kk * P.rs + i] = lu; L.Jc()[i + 12 * i] = luu;
         // y: grf pyramid rows [0 0 1; -1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu] for foot f = i/3
@@ -938,9 +947,9 @@ HD void wb_lq_terminal(WbLqLds& S, PhaseC& P, PhaseC* Pn, const ModelDev& md, in
         return;
     }
     // ---- impact partial (WBM.cpp:508-543)
-    int tdfeet[4]; int ntd = 0; for (int f = 0; f < 4; f++) if (P.td[f]) tdfeet[ntd++] = f;
+    int tdfeet[4] = {0, 0, 0, 0}; int ntd = 0; for (int f = 0; f < 4; f++) if (P.td[f]) tdfeet[ntd++] = f;
     const int m = 3 * ntd;
-    wb_kkt_direct<NT>(L, ntd, tdfeet, 1, 0.0);    // L.qdd = v+, L.lam = impulse_c (compact); factors L (in M), X, Schur factor
+    wb_kkt_direct<NT>(L, ntd, Feet4{tdfeet[0], tdfeet[1], tdfeet[2], tdfeet[3]}, 1, 0.0);    // L.qdd = v+, L.lam = impulse_c (compact); factors L (in M), X, Schur factor
     wb_keep_schur<NT>(L, D);
     // pass A: d(M dv)/dq (v = 0, acc = v+ - v, gravity off) on lanes 0..17; d(J^T imp)/dq with the mis-sliced impulse (quirk v)
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid] - L.x[18 + tid]; if (tid < 12) L.fext[tid] = 0.0;)
