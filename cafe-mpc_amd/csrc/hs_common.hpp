@@ -22,11 +22,12 @@
 #define HD __device__ __forceinline__
 #define HDH __host__ __device__ inline
 #define HS_SHARED __shared__
-// A single-wave workgroup (NT == 64) only ever hands data over through LDS inside a kernel: its phase boundary is the LDS-only
+// The per-knot workgroups (NT == 64 or 128) only ever hand data over through LDS inside a kernel: its phase boundary is the LDS-only
 // barrier (see HS_PHASE_L below) - __syncthreads() would also drain every outstanding global store / prefetch at each of the
 // ~60 phase boundaries of a knot.  Larger workgroups keep the full barrier.
 template <int NT> __device__ __forceinline__ void hs_phase_sync() { __syncthreads(); }
 template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+template <> __device__ __forceinline__ void hs_phase_sync<128>() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the per-knot kernels, one or two waves
 #define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0); if (tid < (NT)) { __VA_ARGS__ } } hs_phase_sync<(NT)>(); }
 // wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program
 // order, so the only thing to prevent is compiler motion across the phase boundary.

@@ -30,6 +30,9 @@ struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
 #else
 #define ROLL_ATTR
 #endif
+#ifndef LQ_NT
+#define LQ_NT 64      // threads of the LQ workgroup (one knot)
+#endif
 #ifdef LQ_WPE
 #define LQ_ATTR __attribute__((amdgpu_waves_per_eu(LQ_WPE, LQ_WPE)))
 #else
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, i
     }
 }
 
-__global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
+__global__ void __launch_bounds__(LQ_NT) LQ_ATTR k_lq(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
                                           const ProbState* st, int mask, int use_cache) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
@@ -90,16 +93,16 @@ __global__ void __launch_bounds__(64) LQ_ATTR k_lq(const PhaseDev* ph_, int nph,
     PhaseC& P = ph[pi];
     if (P.model == HSDDP_MODEL_HKD) {
         HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
-        if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+        if (k < P.h) hkd_lq_knot<LQ_NT>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<LQ_NT>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
         return;
     }
     if (P.model == HSDDP_MODEL_SRB) {
         SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
-        if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
+        if (k < P.h) srb_lq_knot<LQ_NT>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<LQ_NT>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
         return;
     }
-    if (k < P.h) wb_lq_knot<64>(L, P, md, b, k, opt.ReB_active, use_cache != 0);
-    else wb_lq_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+    if (k < P.h) wb_lq_knot<LQ_NT>(L, P, md, b, k, opt.ReB_active, use_cache != 0);
+    else wb_lq_terminal<LQ_NT>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
 }
 
 // cost-only refresh from stored g / h with the CURRENT ReB / AL parameters (SinglePhase::compute_cost, SinglePhase.cpp:236-262)
@@ -501,7 +504,7 @@ static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mas
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_lq");
-    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
+    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(LQ_NT), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
                        h->cache_valid ? 1 : 0);
 }
 static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {

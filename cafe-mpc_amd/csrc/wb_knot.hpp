@@ -377,8 +377,9 @@ HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double 
             wb_pass<Dual, DSink, 1>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
             if (!part) zero_rest(seed, leg);
         }
-        if (tid < 24) {
-            const int t = tid; int seed, leg, slot = 0; const bool part = t < 12;
+        const int kt = (NT >= 128) ? tid - 64 : tid;      // a 128-thread workgroup runs the kinematic round on its second wave, next to the dynamic round
+        if (kt >= 0 && kt < 24) {
+            const int t = kt; int seed, leg, slot = 0; const bool part = t < 12;
             if (part) { const int bs = 3 + (t >> 2); seed = base_seed(bs); leg = t & 3; slot = 4 * bs + leg; }
             else { const int jl = t - 12; seed = 42 + jl; leg = jl / 3; }
             LaneCfg c = lane_cfg(md, true, 0.0, 0.0, 1.0, vscale_kin, ascale_kin, -1, seed - 36, -1);
@@ -759,8 +760,8 @@ HD void wb_cost_gram(WbLqLds& S, double* gvec) {
 #endif
 }
 
-// cache commit: which regions a round of 64 elements (q) touches is known at compile time: no comparison chain per element
-#define KC_REGION(s_, e_, ptr_) if (64 * q + 63 >= (s_) && 64 * q < (e_)) { if (64 * q >= (s_) && 64 * q + 63 < (e_)) (ptr_)[i - (s_)] = v; else if (i >= (s_) && i < (e_)) (ptr_)[i - (s_)] = v; }
+// cache commit: which regions a round of NT elements (q) touches is known at compile time: no comparison chain per element
+#define KC_REGION(s_, e_, ptr_) if (NT * q + NT - 1 >= (s_) && NT * q < (e_)) { if (NT * q >= (s_) && NT * q + NT - 1 < (e_)) (ptr_)[i - (s_)] = v; else if (i >= (s_) && i < (e_)) (ptr_)[i - (s_)] = v; }
 // LQ approximation of knot k < h (recomputes the contact solve at the stored X,U like WBM.cpp:463)
 template <int NT>
 HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int reb_active, bool cached = false) {
@@ -778,10 +779,10 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         const double vw = (tid < 36) ? P.q[tid] : (tid < 48) ? P.r[tid - 36] : 0.0;
         double gr[2], dr[2], er[2];
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; const size_t gi = kk * P.ng + c; const bool in = c < P.ng; gr[q] = in ? P.g[gi] : 1.0; dr[q] = in ? P.delta[gi] : 1.0; er[q] = in ? P.eps[gi] : 0.0; }
-        double r[KC_SIZE / 64];
+        double r[KC_SIZE / NT];
         if (cached) {   // the rollout that produced X[k], U[k] left its contact solve behind: fetch it instead of repeating the terms and the factorisations
             const double* kc = P.kc + kk * KC_SIZE;
-            _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) r[q] = kc[q * 64 + tid];
+            _Pragma("unroll") for (int q = 0; q < KC_SIZE / NT; q++) r[q] = kc[q * NT + tid];
         }
         HS_CBAR();
         if (tid < 36) L.x[tid] = vx; if (tid < 12) { L.u[tid] = vu; L.fext[tid] = 0.0; }
@@ -797,8 +798,8 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         if (cached) {
             // trig table straight from the registers (same values wb_trig would read back from LDS), while the cache reads are in flight
             if (tid < 18) { L.cs[tid] = cos(vx); L.sn[tid] = sin(vx); }
-            _Pragma("unroll") for (int q = 0; q < KC_SIZE / 64; q++) {
-                const int i = q * 64 + tid; const double v = r[q];
+            _Pragma("unroll") for (int q = 0; q < KC_SIZE / NT; q++) {
+                const int i = q * NT + tid; const double v = r[q];
                 KC_REGION(KC_M, KC_X, L.M) KC_REGION(KC_X, KC_LG, L.Xm()) KC_REGION(KC_LG, KC_RDM, D.LGs) KC_REGION(KC_RDM, KC_RDG, L.rdM)
                 KC_REGION(KC_RDG, KC_QDD, D.rdGs) KC_REGION(KC_QDD, KC_GRF, L.qdd) KC_REGION(KC_GRF, KC_LAM, L.grf) KC_REGION(KC_LAM, KC_J, L.lam)
                 KC_REGION(KC_J, KC_FP, L.Jall) KC_REGION(KC_FP, KC_FV, L.fpos) KC_REGION(KC_FV, KC_FV + 12, L.fvel)

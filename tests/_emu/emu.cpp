@@ -10,6 +10,9 @@
 #include <cmath>
 #include <vector>
 #include "hsddp.h"
+#ifndef EMU_LQ_NT
+#define EMU_LQ_NT 64      // threads of the emulated LQ workgroup (the product's LQ_NT)
+#endif
 #include "hs_types.hpp"
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
@@ -102,10 +105,10 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
     OptDev o = to_dev(*opt); static WbLqLds L; static SrbLds Ls; static HkdLds Lh;
     for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
         int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi];
-        if (P.model == HSDDP_MODEL_HKD) { if (k < P.h) hkd_lq_knot<64>(Lh, P, b, k, o.ReB_active); else hkd_lq_terminal<64>(Lh, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active); }
-        else if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<64>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<64>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
-        else if (k < P.h) wb_lq_knot<64>(L, P, h->md, b, k, o.ReB_active, h->cache_valid);
-        else wb_lq_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
+        if (P.model == HSDDP_MODEL_HKD) { if (k < P.h) hkd_lq_knot<EMU_LQ_NT>(Lh, P, b, k, o.ReB_active); else hkd_lq_terminal<EMU_LQ_NT>(Lh, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active); }
+        else if (P.model == HSDDP_MODEL_SRB) { if (k < P.h) srb_lq_knot<EMU_LQ_NT>(Ls, P, b, k, o.ReB_active); else srb_lq_terminal<EMU_LQ_NT>(Ls, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, b); }
+        else if (k < P.h) wb_lq_knot<EMU_LQ_NT>(L, P, h->md, b, k, o.ReB_active, h->cache_valid);
+        else wb_lq_terminal<EMU_LQ_NT>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, o.AL_active);
     }
     return 0;
 }
