@@ -17,6 +17,8 @@
 // wave-level phase: only the first 64 threads of the workgroup run it, ordered by a wave barrier (no s_barrier)
 #define HS_WPHASE(...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
 #define HS_PHASE_L(NT, ...) HS_PHASE(NT, __VA_ARGS__)
+// wave-level phase of wave W of a multi-wave workgroup, tid = lane 0..63 (the emulator runs the waves' phases in program order)
+#define HS_WPHASE_W(W, ...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
@@ -37,6 +39,9 @@ template <> __device__ __forceinline__ void hs_phase_sync<128>() { asm volatile(
 // (tid is laundered through an empty asm so that index arithmetic derived from it is NOT hoisted out of the knot loop and
 // kept live in hundreds of registers / scratch slots)
 #define HS_PHASE_L(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0); if (tid < (NT)) { __VA_ARGS__ } } asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+// wave-level phase of wave W of a multi-wave workgroup, tid = lane 0..63: the waves of a workgroup can run DIFFERENT phase sequences
+// side by side between two workgroup barriers as long as they touch disjoint LDS
+#define HS_WPHASE_W(W, ...) { if ((threadIdx.x >> 6) == (W)) { int tid = threadIdx.x & 63; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0 && tid < 64); { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #define HS_WPHASE(...) { if (threadIdx.x < 64) { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); { __VA_ARGS__ } } __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 #endif
 

@@ -30,14 +30,15 @@ struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
 #else
 #define ROLL_ATTR
 #endif
+// LQ workgroup: 128 threads = two waves per knot (tangent rounds side by side, then column solves || cost partials), capped at 256
+// registers so that the four knots a CU holds in LDS make two waves per SIMD.  LQ_NT=64 is the one-wave variant.
 #ifndef LQ_NT
-#define LQ_NT 64      // threads of the LQ workgroup (one knot)
+#define LQ_NT 128
 #endif
-#ifdef LQ_WPE
+#ifndef LQ_WPE
+#define LQ_WPE 2
+#endif
 #define LQ_ATTR __attribute__((amdgpu_waves_per_eu(LQ_WPE, LQ_WPE)))
-#else
-#define LQ_ATTR
-#endif
 
 // ------------------------------------------------------------------------------------------------ kernels
 enum { MASK_NONE = 0, MASK_LS = 1, MASK_INNER = 2, MASK_OUTER = 3, MASK_LS_OK = 4 };

@@ -650,12 +650,17 @@ HD void wb_cost_prefetch(WbCore& L, PhaseC& P, int k, int tid) {
 // foot-cost Jacobian blocks of the knot: JP (position-type rows, base-translation and velocity columns zero),
 // JW (velocity-type rows [d vel/dq | J]), with per-row weights (dt folded in) and residuals.  `terminal` selects the
 // terminal cost objects (foot-place reg x2, touchdown velocity) instead of the running ones.
+struct WbLqLds;
+HD void wb_cost_blocks_lane(WbLqLds& S, PhaseC& P, bool terminal, int tid);
 template <int NT>
 HD void wb_cost_blocks(WbLqLds& S, PhaseC& P, int k, bool terminal) {
+    (void)k;
+    HS_PHASE(NT, wb_cost_blocks_lane(S, P, terminal, tid);)
+}
+HD void wb_cost_blocks_lane(WbLqLds& S, PhaseC& P, bool terminal, int tid) {
     WbCore& L = S.c; WbDeriv& D = S.d;
     const double* rc = L.red + 28; const double* fp = L.red; const double* bp = L.red + 24;     // wb_cost_prefetch
-    (void)k;
-    HS_PHASE(NT,
+    {
         if (tid < 12) {
             const int f = tid / 3, a = tid % 3;
             double wpos = 0, wvel = 0;
@@ -670,7 +675,8 @@ HD void wb_cost_blocks(WbLqLds& S, PhaseC& P, int k, bool terminal) {
             D.wp[tid] = wpos; D.wv[tid] = wvel;
             D.ep[tid] = (L.fpos[tid] - L.x[a]) - (fp[tid] - bp[a]);
             D.ev[tid] = terminal ? L.fvel[tid] : (L.fvel[tid] - L.red[12 + tid]);
-        })
+        }
+    }
 }
 // column d of  JP^T diag(wp) JP + JW^T diag(wv) JW  written to out[0..35] (stride 36), and the gradient entry.  The blocks are
 // read in place:  JP = [0 | J(:,3:18) | 0] (position-type rows: base-translation and velocity columns zero, MHPCCost.cpp:54-59),
@@ -707,6 +713,35 @@ HD double wb_cost_column(const WbDeriv& D, const double* Jall, const double* dve
     return g;
 }
 
+#ifndef HS_HOST_EMU
+// the 54 MFMAs of the foot-cost product E^T diag(w) [E | e] of one wave: lane (li = lane & 15, lk = lane >> 4) ends up with
+// c[ti][tj][q] = entry (row 16 ti + lk + 4 q, column 16 tj + li)
+HD void wb_cost_gram_acc(WbCore& L, WbDeriv& D, int lane, d4_t (&c)[3][3]) {
+    const int li = lane & 15, lk = lane >> 4;
+    bool anyv = false;
+    _Pragma("unroll") for (int a = 0; a < 12; a++) anyv = anyv || (D.wv[a] != 0.0);
+    _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) c[ti][tj] = d4_t{0.0, 0.0, 0.0, 0.0};
+    _Pragma("unroll") for (int kg = 0; kg < 6; kg++) {
+        if (kg >= 3 && !anyv) break;
+        const int k = 4 * kg + lk, r = (kg < 3) ? k : k - 12;
+        const double w = (kg < 3) ? D.wp[r] : D.wv[r], res = (kg < 3) ? D.ep[r] : D.ev[r];
+        double e[3];
+        _Pragma("unroll") for (int t = 0; t < 3; t++) {
+            const int col = 16 * t + li, cc = col < 36 ? col : 35, lo = cc < 18, c18 = lo ? cc : cc - 18;
+            const double vj = L.Jall[r * 18 + c18];
+            if (kg < 3) e[t] = (cc >= 3 && lo && col < 36) ? vj : 0.0;
+            else { const double vd = L.dvel()[r * 18 + c18]; e[t] = col < 36 ? (lo ? vd : vj) : 0.0; }
+        }
+        _Pragma("unroll") for (int ti = 0; ti < 3; ti++) {
+            const double a = w * e[ti];
+            _Pragma("unroll") for (int tj = 0; tj < 3; tj++) {
+                const double bb = (tj == 2 && li == 4) ? res : e[tj];      // column 36: the residual -> gradient
+                c[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c[ti][tj], 0, 0, 0);
+            }
+        }
+    }
+}
+#endif
 // Foot-cost Hessian and gradient of a knot on the fp64 matrix cores (one wave).  With E the 24 x 36 matrix of cost rows
 //   rows 0..11  (position type, weight wp, residual ep): [0 0 0 | J(3f+r, 3:18) | 0]      (MHPCCost.cpp:54-59)
 //   rows 12..23 (velocity type, weight wv, residual ev): [d(foot vel)/dq | J(3f+r, :)]
@@ -729,29 +764,8 @@ HD void wb_cost_gram(WbLqLds& S, double* gvec) {
 #else
     HS_PHASE_L(NT, if (tid < 64) {
         const int li = tid & 15, lk = tid >> 4;
-        bool anyv = false;
-        _Pragma("unroll") for (int a = 0; a < 12; a++) anyv = anyv || (D.wv[a] != 0.0);
         d4_t c[3][3];
-        _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) c[ti][tj] = d4_t{0.0, 0.0, 0.0, 0.0};
-        _Pragma("unroll") for (int kg = 0; kg < 6; kg++) {
-            if (kg >= 3 && !anyv) break;
-            const int k = 4 * kg + lk, r = (kg < 3) ? k : k - 12;
-            const double w = (kg < 3) ? D.wp[r] : D.wv[r], res = (kg < 3) ? D.ep[r] : D.ev[r];
-            double e[3];
-            _Pragma("unroll") for (int t = 0; t < 3; t++) {
-                const int col = 16 * t + li, cc = col < 36 ? col : 35, lo = cc < 18, c18 = lo ? cc : cc - 18;
-                const double vj = L.Jall[r * 18 + c18];
-                if (kg < 3) e[t] = (cc >= 3 && lo && col < 36) ? vj : 0.0;
-                else { const double vd = L.dvel()[r * 18 + c18]; e[t] = col < 36 ? (lo ? vd : vj) : 0.0; }
-            }
-            _Pragma("unroll") for (int ti = 0; ti < 3; ti++) {
-                const double a = w * e[ti];
-                _Pragma("unroll") for (int tj = 0; tj < 3; tj++) {
-                    const double bb = (tj == 2 && li == 4) ? res : e[tj];      // column 36: the residual -> gradient
-                    c[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c[ti][tj], 0, 0, 0);
-                }
-            }
-        }
+        wb_cost_gram_acc(L, D, tid, c);
         _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) _Pragma("unroll") for (int q = 0; q < 4; q++) {
             const int row = 16 * ti + lk + 4 * q, col = 16 * tj + li;
             if (row < 36) { if (col < 36) D.W[row * 36 + col] = c[ti][tj][q]; else if (col == 36) gvec[row] = c[ti][tj][q]; }
@@ -820,6 +834,118 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid]; if (tid < 12) L.fext[tid] = L.grf[tid];)
     wb_dpass<NT>(L, D, md, GRAV, 1.0, 1.0, 1.0, false);
     LQ_STAMP(2)
+    if (NT >= 128) {
+        // ---- two waves, two jobs, no workgroup barrier in between (disjoint LDS): wave 0 solves the 48 KKT columns and copies A, B, C, D
+        // out; wave 1 forms every cost partial of the knot meanwhile and stores lxx / lx straight from the matrix-core accumulators
+        HS_WPHASE_W(0, if (tid < 48) {
+        const int d = tid;
+        double top[18], bot[12];
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0)) : ((i == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) {
+            bot[a] = 0.0;
+            if (a < m) {      // uniform over the wave; the q / v halves differ only in which arrays feed the two terms: selects, no divergent branches
+                const int r = 3 * P.feet[a / 3] + a % 3, dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18;
+                const double vg = L.G()[r * 18 + c], vd = L.dvel()[r * 18 + c], vj = L.Jall[r * 18 + c];
+                const double t1 = dc < 18 ? vg : 2.0 * vd, t2 = dc < 18 ? vd : vj;       // footAccPartialDv == 2 footVelPartialDq
+                bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
+            }
+        }
+        wb_kkt_column(L, D, top, bot, false);
+        if (d < 36) {
+            _Pragma("unroll")
+            for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = -top[i] * dt + ((d == 18 + i) ? 1.0 : 0.0);     // rows 18..35 of A
+            _Pragma("unroll")
+            for (int a = 0; a < 12; a++) D.stC()[a + 12 * d] = 0.0;
+            for (int a = 0; a < m; a++) D.stC()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = bot[a];
+        } else {
+            const int j = d - 36;
+            _Pragma("unroll")
+            for (int i = 0; i < 18; i++) D.stB()[i + 18 * j] = top[i] * dt;
+            _Pragma("unroll")
+            for (int a = 0; a < 12; a++) D.stD()[a + 12 * j] = 0.0;
+            for (int a = 0; a < m; a++) D.stD()[(3 * P.feet[a / 3] + a % 3) + 12 * j] = -bot[a];
+        }
+        })
+        LQ_STAMP(3)
+        HS_WPHASE_W(0,
+            store_image<64, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
+            store_image<64, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
+            store_image<64, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
+            store_image<64, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
+        LQ_STAMP(4)
+        // wave 1.  Scratch in the free Jc block of JX (the columns only read Xm): [0,36) lx without the foot terms | [36,72) diagonal
+        // additions | [72,84) luu diagonal | [84,120) lyy 3x3 blocks (r' + 3 column) | [120,156) foot-cost gradient (emulator only)
+        double* const T1 = L.Jc();
+        HS_WPHASE_W(1, wb_cost_blocks_lane(S, P, false, tid);
+            if (tid < 36) {
+                const int d = tid;
+                double lxd = dt * L.wq[d] * (L.x[d] - L.tmp[d]);
+                double diag = dt * L.wq[d];
+                if (P.go_joint >= 0 && d >= 6 && d < 18) {
+                    const int i = d - 6;
+                    lxd += dt * (D.bd()[P.go_joint + i] - D.bd()[P.go_joint + 12 + i]); diag += dt * (D.bdd()[P.go_joint + i] + D.bdd()[P.go_joint + 12 + i]);
+                }
+                if (P.go_height >= 0 && d == 2) { lxd += dt * D.bd()[P.go_height]; diag += dt * D.bdd()[P.go_height]; }
+                if (P.go_jspeed >= 0 && d >= 24) {
+                    const int i = d - 24;
+                    lxd += dt * (D.bd()[P.go_jspeed + i] - D.bd()[P.go_jspeed + 12 + i]); diag += dt * (D.bdd()[P.go_jspeed + i] + D.bdd()[P.go_jspeed + 12 + i]);
+                }
+                T1[d] = lxd; T1[36 + d] = diag;
+            })
+#ifdef HS_HOST_EMU
+        // (the emulator runs wave 0's phases first, so the dense tile of W is free here; same transposed placement as the GPU path)
+        HS_WPHASE_W(1, if (tid < 37) {
+            const int j = tid;
+            auto E = [&](int k2, int c) { if (k2 < 12) return (c >= 3 && c < 18) ? L.Jall[k2 * 18 + c] : 0.0; const int r = k2 - 12; return c < 18 ? L.dvel()[r * 18 + c] : L.Jall[r * 18 + c - 18]; };
+            for (int i = 0; i < 36; i++) {
+                double sm = 0;
+                for (int k2 = 0; k2 < 24; k2++) { const double w = k2 < 12 ? D.wp[k2] : D.wv[k2 - 12]; sm += w * E(k2, i) * (j < 36 ? E(k2, j) : (k2 < 12 ? D.ep[k2] : D.ev[k2 - 12])); }
+                if (j < 36) D.W[i * 36 + j] = sm; else T1[120 + i] = sm;
+            }
+        })
+        HS_WPHASE_W(1, if (tid < 36) { D.W[tid * 36 + tid] += T1[36 + tid]; P.lx[kk * P.rs + tid] = T1[tid] + T1[120 + tid]; })
+        HS_WPHASE_W(1, store_image<64, 1296, 36>(P.lxx + kk * P.rs, tid, [&](int, int r, int c) { return D.W[c * 36 + r]; });)
+#else
+        HS_WPHASE_W(1, {
+            const int li = tid & 15, lk = tid >> 4;
+            d4_t c[3][3];
+            wb_cost_gram_acc(L, D, tid, c);
+            // entry (row, col) goes to the TRANSPOSED position col + 36 row (lxx is symmetric; the 16 lanes of a row write 128 contiguous bytes)
+            _Pragma("unroll") for (int ti = 0; ti < 3; ti++) _Pragma("unroll") for (int tj = 0; tj < 3; tj++) _Pragma("unroll") for (int q = 0; q < 4; q++) {
+                const int row = 16 * ti + lk + 4 * q, col = 16 * tj + li;
+                if (row < 36) {
+                    if (col < 36) { double v = c[ti][tj][q]; if (row == col) v += T1[36 + row]; P.lxx[kk * P.rs + col + 36 * row] = v; }
+                    else if (col == 36) P.lx[kk * P.rs + row] = T1[row] + c[ti][tj][q];
+                }
+            }
+        })
+#endif
+        // lu, luu (diagonal + torque barrier), ly, lyy (grf barrier: one 3x3 block per foot)
+        HS_WPHASE_W(1, if (tid < 12) {
+            const int i = tid;
+            double lu = dt * L.wq[36 + i] * (L.u[i] - L.tmp[36 + i]), luu = dt * L.wq[36 + i];
+            if (P.go_torque >= 0) { lu += dt * (-D.bd()[P.go_torque + i] + D.bd()[P.go_torque + 12 + i]); luu += dt * (D.bdd()[P.go_torque + i] + D.bdd()[P.go_torque + 12 + i]); }
+            P.lu[kk * P.rs + i] = lu; T1[72 + i] = luu;
+            double ly = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0; const int f = i / 3, r = i % 3; int a = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a = t;
+            if (P.go_grf >= 0 && a >= 0) {
+                const double mu = P.mu;
+                for (int c = 0; c < 5; c++) {
+                    const double r0 = (c == 1) ? -1.0 : (c == 2) ? 1.0 : 0.0, r1 = (c == 3) ? -1.0 : (c == 4) ? 1.0 : 0.0, r2 = (c == 0) ? 1.0 : mu;
+                    const double rr = (r == 0) ? r0 : (r == 1) ? r1 : r2;
+                    const double hb = dt * D.bdd()[P.go_grf + 5 * a + c] * rr;
+                    ly += D.bd()[P.go_grf + 5 * a + c] * rr;
+                    b0 += hb * r0; b1 += hb * r1; b2 += hb * r2;
+                }
+            }
+            T1[84 + 3 * i] = b0; T1[85 + 3 * i] = b1; T1[86 + 3 * i] = b2;
+            P.ly[kk * P.rs + i] = dt * ly;
+        })
+        HS_WPHASE_W(1, store_image<64, 144, 12>(P.luu + kk * P.rs, tid, [&](int, int r, int c) { return r == c ? T1[72 + r] : 0.0; });
+                       store_image<64, 144, 12>(P.lyy + kk * P.rs, tid, [&](int, int r, int c) { return (r / 3 == c / 3) ? T1[84 + (r % 3) + 3 * c] : 0.0; });)
+        return;
+    }
     // lane d < 36: column d of the continuous partials, right-hand side top = d tau - d(J^T F) (18), bot = d(foot acc) + Baumgarte
     // terms (m) -> column d of A (rows 18..35) and of C ; lanes 36..47: unit torque j -> column j of B and of D
     HS_PHASE(NT, if (tid < 48) {
