@@ -25,10 +25,11 @@ if hasattr(lib, "hsddp_debug_sweep_prof"):
     lib.hsddp_debug_sweep_prof(buf, 1)
     s.backward_sweep(0.0)
     lib.hsddp_debug_sweep_prof(buf, 0)
-    names = ["load", "HA/HB", "Qxx/Qux/Quu", "reg+store", "store Quu/Qux", "chol+inv", "symm", "K,dU", "H,G", "store K"]
+    names = ["commit + next fetch", "phase 1: HA, HB, lC, lD", "phase 2: Qxx, Qux, Quu", "reg + store Qu/Quu/Qux", "chol + K, dU solves", "symmetrise Qxx", "ok check",
+             "H, G update", "store K"]
     tot = sum(buf)
-    for i, n in enumerate(names[:9] if False else names):
-        if i < 16: print(f"  stamp {i} {n:16s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
+    for i, n in enumerate(names):
+        print(f"  stamp {i} {n:26s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
 if hasattr(lib, "hsddp_debug_lq_prof") and os.environ.get("ROLL_PROF"):
     buf = (ctypes.c_ulonglong * 16)()
     lib.hsddp_debug_lq_prof(buf, 1)
