@@ -221,7 +221,7 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
-    static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M, "sweep limits");
+    static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
     constexpr int LDN = ST::LDN, LDM = ST::LDM;
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
@@ -256,13 +256,14 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
             const int w = tid >> 6, lane = tid & 63;
             switch (w) { case 0: sweep_tiles2<0, N, M, PY>(S, lane); break; case 1: sweep_tiles2<1, N, M, PY>(S, lane); break;
                          case 2: sweep_tiles2<2, N, M, PY>(S, lane); break; default: sweep_tiles2<3, N, M, PY>(S, lane); }
-            if (tid < N) {
-                double s = 0;
-                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, tid, LDN) * S.Gn[t];
-                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, tid, LDM) * S.ly[t]; }
-                S.Qx[tid] += s;
-            } else if (tid >= 64 && tid < 64 + M) {
-                const int a = tid - 64; double s = 0;
+            // the two mat-vec chains ride on waves 2 and 3, which carry two tiles each in this phase (waves 0 and 1: three)
+            if (tid >= 128 && tid < 128 + N) {
+                const int i = tid - 128; double s = 0;
+                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
+                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
+                S.Qx[i] += s;
+            } else if (tid >= 192 && tid < 192 + M) {
+                const int a = tid - 192; double s = 0;
                 _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
                 S.Qu[a] += s;
