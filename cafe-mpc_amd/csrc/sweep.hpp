@@ -217,6 +217,21 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
     mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4>(lane, td);
 }
 
+// H = Qxx + Qux^T K : the TN x TN tiles dealt round-robin, a wave's tiles interleaved (their short accumulation chains overlap)
+template <int W, int N, int M, int PY>
+HD void sweep_tiles3(SweepLdsT<N, M, PY>& S, int lane) {
+    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
+    constexpr int TN = (N + 15) / 16;
+    constexpr int NTL = (TN * TN - W + 3) / 4;
+    if (NTL <= 0) return;
+    MTile td[NTL > 0 ? NTL : 1];
+    _Pragma("unroll") for (int q = 0; q < NTL; q++) {
+        const int t = W + 4 * q;
+        td[q] = MTile{S.H, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};
+    }
+    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0>(lane, td);
+}
+
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
@@ -301,7 +316,8 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
-              for (int tile = w; tile < TN * TN; tile += 4) mfma_tile<true, M>(lane, S.H, LDN, S.Qxx, LDN, 16 * (tile % TN), 16 * (tile / TN), N, N, S.Qux, LDM, S.K, LDM); }
+              switch (w) { case 0: sweep_tiles3<0, N, M, PY>(S, lane); break; case 1: sweep_tiles3<1, N, M, PY>(S, lane); break;
+                           case 2: sweep_tiles3<2, N, M, PY>(S, lane); break; default: sweep_tiles3<3, N, M, PY>(S, lane); } }
             if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
             else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); gdU[kk * M + a] = S.dU[a]; })
