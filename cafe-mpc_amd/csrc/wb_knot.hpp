@@ -869,12 +869,6 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         }
         })
         LQ_STAMP(3)
-        HS_WPHASE_W(0,
-            store_image<64, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
-            store_image<64, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
-            store_image<64, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
-            store_image<64, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
-        LQ_STAMP(4)
         // wave 1.  Scratch in the free Jc block of JX (the columns only read Xm): [0,36) lx without the foot terms | [36,72) diagonal
         // additions | [72,84) luu diagonal | [84,120) lyy 3x3 blocks (r' + 3 column) | [120,156) foot-cost gradient (emulator only)
         double* const T1 = L.Jc();
@@ -895,18 +889,19 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
                 T1[d] = lxd; T1[36 + d] = diag;
             })
 #ifdef HS_HOST_EMU
-        // (the emulator runs wave 0's phases first, so the dense tile of W is free here; same transposed placement as the GPU path)
+        // (the emulator has no accumulator registers: a host-side tile stands in for them; same transposed placement as the GPU path)
+        static double emu_tile[1296];
         HS_WPHASE_W(1, if (tid < 37) {
             const int j = tid;
             auto E = [&](int k2, int c) { if (k2 < 12) return (c >= 3 && c < 18) ? L.Jall[k2 * 18 + c] : 0.0; const int r = k2 - 12; return c < 18 ? L.dvel()[r * 18 + c] : L.Jall[r * 18 + c - 18]; };
             for (int i = 0; i < 36; i++) {
                 double sm = 0;
                 for (int k2 = 0; k2 < 24; k2++) { const double w = k2 < 12 ? D.wp[k2] : D.wv[k2 - 12]; sm += w * E(k2, i) * (j < 36 ? E(k2, j) : (k2 < 12 ? D.ep[k2] : D.ev[k2 - 12])); }
-                if (j < 36) D.W[i * 36 + j] = sm; else T1[120 + i] = sm;
+                if (j < 36) emu_tile[i * 36 + j] = sm; else T1[120 + i] = sm;
             }
         })
-        HS_WPHASE_W(1, if (tid < 36) { D.W[tid * 36 + tid] += T1[36 + tid]; P.lx[kk * P.rs + tid] = T1[tid] + T1[120 + tid]; })
-        HS_WPHASE_W(1, store_image<64, 1296, 36>(P.lxx + kk * P.rs, tid, [&](int, int r, int c) { return D.W[c * 36 + r]; });)
+        HS_WPHASE_W(1, if (tid < 36) { emu_tile[tid * 36 + tid] += T1[36 + tid]; P.lx[kk * P.rs + tid] = T1[tid] + T1[120 + tid]; })
+        HS_WPHASE_W(1, store_image<64, 1296, 36>(P.lxx + kk * P.rs, tid, [&](int, int r, int c) { return emu_tile[c * 36 + r]; });)
 #else
         HS_WPHASE_W(1, {
             const int li = tid & 15, lk = tid >> 4;
@@ -944,6 +939,14 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         })
         HS_WPHASE_W(1, store_image<64, 144, 12>(P.luu + kk * P.rs, tid, [&](int, int r, int c) { return r == c ? T1[72 + r] : 0.0; });
                        store_image<64, 144, 12>(P.lyy + kk * P.rs, tid, [&](int, int r, int c) { return (r / 3 == c / 3) ? T1[84 + (r % 3) + 3 * c] : 0.0; });)
+        // wave 1 has been done for a while when wave 0 leaves the column solves: both copy A, B, C, D out
+        hs_phase_sync_all<NT>();
+        HS_PHASE_L(NT,
+            store_image<NT, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
+            store_image<NT, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
+            store_image<NT, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
+            store_image<NT, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
+        LQ_STAMP(4)
         return;
     }
     // lane d < 36: column d of the continuous partials, right-hand side top = d tau - d(J^T F) (18), bot = d(foot acc) + Baumgarte
