@@ -16,6 +16,7 @@ struct MTile {
     const double* A2; int lda2; const double* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
     bool TB = false;
     bool TC = false;      // C(i,j) (and Cin) at C[j + ldc*i] instead of C[i + ldc*j]
+    double dadd = 0.0;    // added to the entries C(i,i) of the tile's block (i.e. where the absolute row equals the absolute column)
 };
 template <int NTL, int KMAX, int KMAX2>
 HD void mfma_tiles(int lane, const MTile* td) {
@@ -34,7 +35,7 @@ HD void mfma_tiles(int lane, const MTile* td) {
     for (int t = 0; t < NTL; t++) {
         const MTile& T = td[t];
         for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
-            const double v = res[t][(i - T.i0) + 16 * (j - T.j0)];
+            const double v = res[t][(i - T.i0) + 16 * (j - T.j0)] + ((i == j) ? T.dadd : 0.0);
             if (T.TC) T.Cout[j + T.ldc * i] = v; else T.Cout[i + T.ldc * j] = v;
         }
     }
@@ -64,7 +65,7 @@ HD void mfma_tiles(int lane, const MTile* td) {
     }
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
         const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; if (row < td[t].M_ && j < td[t].N_) { if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = c[t][r]; else td[t].Cout[row + td[t].ldc * j] = c[t][r]; } }
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; if (row < td[t].M_ && j < td[t].N_) { const double v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
     }
 #endif
 }

@@ -197,7 +197,7 @@ HD void sweep_tiles1(SweepLdsT<N, M, PY>& S, int lane) {
     mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, 0>(lane, td);
 }
 template <int W, int N, int M, int PY>
-HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
+HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane, double reg) {
     constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
@@ -210,9 +210,9 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane) {
         const int t = W + 4 * q;
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
-        if (t < t1) td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY};
+        if (t < t1) { td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg; }     // regularisation on Qxx as well: quirk x
         else if (t < t2) td[q] = MTile{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
-        else td[q] = MTile{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY};
+        else { td[q] = MTile{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
     }
     mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4>(lane, td);
 }
@@ -269,8 +269,8 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles2<0, N, M, PY>(S, lane); break; case 1: sweep_tiles2<1, N, M, PY>(S, lane); break;
-                         case 2: sweep_tiles2<2, N, M, PY>(S, lane); break; default: sweep_tiles2<3, N, M, PY>(S, lane); }
+            switch (w) { case 0: sweep_tiles2<0, N, M, PY>(S, lane, reg); break; case 1: sweep_tiles2<1, N, M, PY>(S, lane, reg); break;
+                         case 2: sweep_tiles2<2, N, M, PY>(S, lane, reg); break; default: sweep_tiles2<3, N, M, PY>(S, lane, reg); }
             // the two mat-vec chains ride on waves 2 and 3, which carry two tiles each in this phase (waves 0 and 1: three)
             if (tid >= 128 && tid < 128 + N) {
                 const int i = tid - 128; double s = 0;
@@ -285,10 +285,9 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
             }
         })
         SW_STAMP(2)
-        // regularisation on Quu; store Qu / Quu / Qux as the reference keeps them (callers read them)
-        HS_PHASE_L(NT, if (tid < M) { CM(S.Quu, tid, tid, LDM) += reg; gQu[kk * M + tid] = S.Qu[tid]; }
-                   else if (tid >= 64 && tid < 64 + N) CM(S.Qxx, tid - 64, tid - 64, LDN) += reg;)     // regularisation on Qxx as well: quirk x
-        HS_PHASE_L(NT, st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
+        // (the regularisation of Quu and Qxx went onto the diagonals with the tiles' stores) ; store Qu / Quu / Qux as the reference keeps them
+        HS_PHASE_L(NT, if (tid < M) gQu[kk * M + tid] = S.Qu[tid];
+                   st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
         chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &SWC.ok);
