@@ -11,7 +11,7 @@
 #include <vector>
 #include "hsddp.h"
 #ifndef EMU_LQ_NT
-#define EMU_LQ_NT 128     // threads of the emulated LQ workgroup (the product's LQ_NT)
+#define EMU_LQ_NT 128     // (default: the product configuration) threads of the emulated LQ workgroup (the product's LQ_NT)
 #endif
 #include "hs_types.hpp"
 #include "hs_host.hpp"

@@ -53,3 +53,15 @@ def test_kernel_programs_match_oracle(emu_lib, oracle_lib, which):
     # the barrel-roll iterate after a full step from the zero-torque start is badly conditioned (cond(Quu) ~ 1e6): Cholesky here vs
     # pivoted LDLT in the oracle differ by ~1e-8 relative in dU; K stays inside the 1e-6 absolute bound of north_star
     pc.run_steps(pkg, so, se, phases, opt, n_iter=2, rtol=1e-6 if which == "barrel_roll" else 1e-8)
+
+
+def test_one_wave_lq_variant_matches_oracle(oracle_lib):
+    """The LQ knot also exists as a one-wave program (LQ_NT=64: tangent rounds one after the other, no wave-level phase sequences);
+    the product builds the two-wave one (LQ_NT=128, what every other test here emulates)."""
+    d = os.path.join(ROOT, "tests", "_emu")
+    subprocess.check_call(["make", "-C", d, "-s", "libhsddp_emu64.so"])
+    emu64 = pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu64.so")))
+    phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+    x0 = pkg.problems.wb_ensemble_x0(2, 20241222)
+    so, se = pc.make_pair(pkg, oracle_lib, emu64, phases, x0)
+    pc.run_steps(pkg, so, se, phases, pkg.mhpc_ddp_setting(), n_iter=2, rtol=1e-8)
