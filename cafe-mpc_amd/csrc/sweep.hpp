@@ -5,19 +5,20 @@
 //                   and SinglePhase::backward_sweep (SinglePhase.cpp:323-391)
 //   (k_sweep)       MultiPhaseDDP::backward_sweep_regularized (MultiPhaseDDP.cpp:136-165) wraps it in the retry loop
 //   linear_rollout  MultiPhaseDDP::linear_rollout (MultiPhaseDDP.cpp:12-42) + SinglePhase::linear_rollout (SinglePhase.cpp:145-178)
-// Quu^-1: the reference uses Eigen's pivoted LDLT of (Quu - 1e-9 I) and rejects on a negative pivot
-// (SinglePhase.cpp:366-375).  Here: unpivoted Cholesky of the same shifted matrix; by Sylvester's law of inertia the
-// accept/reject decision is the same (a non-positive pivot <=> not positive definite), the inverse agrees to rounding.
+// Quu^-1: Eigen's pivoted LDLT of (Quu + reg I - 1e-9 I), PD test = no negative pivot, Quu_inv = LDLT.solve(I), then
+// K = -Quu_inv Qux, dU = -Quu_inv Qu exactly as SinglePhase.cpp:366-380 does (ldlt_inverse_w below restates
+// Eigen/src/Cholesky/LDLT.h ldlt_inplace<Lower>::unblocked + _solve_impl for one wave).
 // lux is identically zero for every cost the reference ships (SinglePhaseInterface.cpp:47, MHPCCost.cpp) and is not stored.
 //
 // MI355X structure (dims are template constants: whole body 36/12/12):
-//  * LDS: every matrix column-major with an ODD padded leading dimension (37 / 13): the register tiles of a wave then hit
+//  * LDS: every matrix column-major with an ODD padded leading dimension (37 / 13): the 16x16 operand tiles of a wave then hit
 //    distinct bank pairs also in the transposed products (A^T HA, B^T HB, C^T lyy C ...).
-//  * each thread owns one 3x3 or 3x2 output tile, inner dimension fully unrolled (loads batched ahead of the FMAs).
-//  * the NEXT knot's 32 KB (A, lxx, B, C, D, luu, lyy, vectors) is prefetched from HBM into 20 registers per thread
+//  * every matrix product of a knot runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64), 16x16 output tiles dealt over the
+//    four waves of the workgroup (hs_mfma.hpp); the mat-vec chains ride on the lanes of the waves that carry fewer tiles.
+//  * the NEXT knot's record (A, lxx, B, C, D, luu, lyy, vectors) is prefetched from HBM into 20 registers per thread
 //    while the current knot computes, and committed to LDS at the top of the next iteration: HBM latency is off the
 //    sequential critical path.
-//  * the 12x12 Cholesky + inverse runs inside wave 0 with unrolled register recurrences (no workgroup barrier).
+//  * the 12x12 (24x24) LDLT + inverse runs inside wave 0: rows in registers, pivots and multipliers by lane broadcast.
 #pragma once
 #include <cstddef>
 #include "hs_types.hpp"
@@ -78,36 +79,6 @@ __device__ unsigned long long g_sw_prof[16];
 #define PRE(r) pre_[r]
 #endif
 
-// One 16x16 output tile per WAVE on the fp64 matrix cores:  Cout(i,j) = (Cin ? Cin(i,j) : 0) + sum_t opA(i,t) * B(t,j)
-// (v_mfma_f64_16x16x4_f64: lane l feeds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns C rows (l>>4) + 4r, column l&15).
-// Each MFMA performs 1024 FMAs from 2 LDS reads per lane (1 B/FMA); the 3x3 VALU register tile needs 5.3 B/FMA and was
-// LDS-bandwidth bound.  Rows/cols beyond M_/N_ (36 = 2.25 tiles) are fed zeros / not stored.
-template <bool TA, int K>
-HD void mfma_tile(int lane, double* Cout, int ldc, const double* Cin, int ldcin, int i0, int j0, int M_, int N_,
-                  const double* A, int lda, const double* B, int ldb) {
-#ifdef HS_HOST_EMU
-    if (lane != 0) return;     // the emulator lets lane 0 stand for the wave (plain loops); the lane mapping is verified on the GPU
-    for (int j = j0; j < j0 + 16 && j < N_; j++) for (int i = i0; i < i0 + 16 && i < M_; i++) {
-        double s = Cin ? Cin[i + ldcin * j] : 0.0;
-        for (int t = 0; t < K; t++) s += (TA ? A[t + lda * i] : A[i + lda * t]) * B[t + ldb * j];
-        Cout[i + ldc * j] = s;
-    }
-#else
-    static_assert(K % 4 == 0, "K must be a multiple of 4");
-    const int li = lane & 15, lk = lane >> 4, i = i0 + li, j = j0 + li;
-    const bool iv = i < M_, jv = j < N_;
-    d4_t c;
-    _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; c[r] = (Cin && row < M_ && jv) ? Cin[row + ldcin * j] : 0.0; }
-    _Pragma("unroll") for (int kg = 0; kg < K / 4; kg++) {
-        const int k = 4 * kg + lk;
-        const double a = iv ? (TA ? A[k + lda * i] : A[i + lda * k]) : 0.0;
-        const double b = jv ? B[k + ldb * j] : 0.0;
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = i0 + lk + 4 * r; if (row < M_ && jv) Cout[row + ldc * j] = c[r]; }
-#endif
-}
-
 // Sum over the 4 lanes of an aligned quad in the order (p0 + p1) + (p2 + p3), by two DPP quad permutes (no LDS traffic); every
 // lane of the quad receives the sum.  The linear rollout is a chain of mat-vec products: splitting each row over a quad cuts the
 // dependent multiply-add chain of a knot by four.
@@ -131,24 +102,120 @@ HD double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); r
     const double total = quad_sum(partial); const double total2 = quad_sum(partial2); (void)total2; if (part == 0) FINISH }
 #endif
 
-// ---- wave-level (wave 0) factorisation helpers, compile-time size, recurrences in registers -------------------
-template <int N, int LD>
-HD void chol_w(const double* A, double* Lo, double* rd, double diag_add, int* ok) {
-#ifndef HS_HOST_EMU
-    HS_WPHASE(chol_r<N, LD>(A, 1, LD, Lo, rd, diag_add, tid, ok);)     // rows in registers, lane broadcasts (hs_common.hpp)
-    return;
+// ---- wave 0: Eigen's pivoted LDLT and the explicit inverse ------------------------------------------------------------------
+// What the reference does per knot (SinglePhase.cpp:366-375): Eigen::LDLT<DMat>::compute(Quu - 1e-9 I), isPositive(), solve(I).
+// Eigen 3.3's ldlt_inplace<Lower>::unblocked (third-party, restated from its published source; the CPU checker holds the same
+// restatement):
+//   step k: the pivot is the FIRST largest |diagonal| among rows k.. of the working matrix - and since a left-looking step only
+//   ever rewrites column k, those diagonals are still the ORIGINAL ones: the pivot order is a selection sort of the original
+//   |diagonal| (with Eigen's swap dynamics deciding exact ties);  symmetric swap;  temp_j = D_j L(k,j);  A(k,k) -= L(k,:) temp;
+//   A(k+1:,k) = (A(k+1:,k) - L(k+1:,:) temp) / A(k,k);  sign bookkeeping.  Only the lower triangle of the input is read.
+//   solve: x = P b; unit-lower forward substitution; x_i = |D_i| > 1/DBL_MAX ? x_i / D_i : 0; backward substitution; x = P^T x.
+// Wave mapping: lane i owns ROW i of the PERMUTED matrix.  The pivot order comes first (each lane ranks its own diagonal entry; an
+// exact tie - symmetric problems - sends the wave through the literal selection sort instead).  Then the left-looking steps with
+// the row's multipliers in registers: L(k,j) and the pivot travel by constant-lane broadcasts (v_readlane), every entry sees the
+// same sequence of multiply-adds as in Eigen's loops.  The multipliers go to LDS once, and lanes 0..M-1 each solve one column of
+// the identity.  Output: NI = -(A + diag_add I)^-1 (the sign the gains need), column-major with leading dimension LD.
+// Scratch: Lw >= M*M doubles, iw >= M ints.
+template <int M, int LD>
+HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw, int* iw, int* ok) {
+    constexpr double TOL = 1.0 / 1.7976931348623157e308;
+#ifdef HS_HOST_EMU
+    HS_WPHASE(if (tid == 0) {      // the emulator has no lanes to broadcast between: Eigen's loops as they stand, with physical swaps
+        double m[M * M]; int tr[M]; int sign = 0; (void)Lw; (void)iw;
+        for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) m[i + M * j] = A[i + LD * j] + (i == j ? diag_add : 0.0);
+        auto Mx = [&](int i, int j) -> double& { return m[i + M * j]; };
+        double temp[M];
+        for (int k = 0; k < M; k++) {
+            int big = k; double best = std::fabs(Mx(k, k));
+            for (int i = k + 1; i < M; i++) if (std::fabs(Mx(i, i)) > best) { best = std::fabs(Mx(i, i)); big = i; }
+            tr[k] = big;
+            if (k != big) {
+                for (int j = 0; j < k; j++) { const double t = Mx(k, j); Mx(k, j) = Mx(big, j); Mx(big, j) = t; }
+                for (int i = big + 1; i < M; i++) { const double t = Mx(i, k); Mx(i, k) = Mx(i, big); Mx(i, big) = t; }
+                { const double t = Mx(k, k); Mx(k, k) = Mx(big, big); Mx(big, big) = t; }
+                for (int i = k + 1; i < big; i++) { const double t = Mx(i, k); Mx(i, k) = Mx(big, i); Mx(big, i) = t; }
+            }
+            for (int j = 0; j < k; j++) temp[j] = Mx(j, j) * Mx(k, j);
+            { double s = 0; for (int j = 0; j < k; j++) s += Mx(k, j) * temp[j]; Mx(k, k) -= s; }
+            for (int i = k + 1; i < M; i++) { double t = 0; for (int j = 0; j < k; j++) t += Mx(i, j) * temp[j]; Mx(i, k) -= t; }
+            const double akk = Mx(k, k); const bool valid = std::fabs(akk) > 0.0;
+            if (valid) for (int i = k + 1; i < M; i++) Mx(i, k) /= akk;
+            if (sign == 1) { if (akk < 0) sign = 2; } else if (sign == -1) { if (akk > 0) sign = 2; } else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+        }
+        if (!(sign == 1 || sign == 0)) *ok = 0;
+        for (int c = 0; c < M; c++) {
+            double x[M]; for (int i = 0; i < M; i++) x[i] = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < M; k++) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+            for (int i = 0; i < M; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= Mx(i, j) * x[j]; x[i] = s; }
+            for (int i = 0; i < M; i++) { const double d = Mx(i, i); x[i] = (std::fabs(d) > TOL) ? x[i] / d : 0.0; }
+            for (int i = M - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < M; j++) s -= Mx(j, i) * x[j]; x[i] = s; }
+            for (int k = M - 1; k >= 0; k--) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+            for (int i = 0; i < M; i++) NI[i + LD * c] = -x[i];
+        }
+    })
+#else
+    static_assert(M <= 32, "one row per lane");
+    HS_WPHASE({
+        const bool act = tid < M; const int me = act ? tid : M - 1;       // idle lanes mirror the last row (all 64 lanes run the broadcasts)
+        // ---- pivot order
+        double dg[M];
+        _Pragma("unroll") for (int j = 0; j < M; j++) dg[j] = fabs(A[j + LD * j] + diag_add);
+        const double mine = fabs(A[me + LD * me] + diag_add);
+        int rank = 0; bool tie = false;
+        _Pragma("unroll") for (int j = 0; j < M; j++) { const bool eq = (dg[j] == mine) && (j != me); rank += (dg[j] > mine || (eq && j < me)) ? 1 : 0; tie = tie || eq; }
+        if (__builtin_amdgcn_ballot_w64(tie && act) == 0ull) { if (act) iw[rank] = me; }
+        else {      // exact ties: Eigen's selection with swaps, literally, on wave-uniform registers
+            double v[M]; int ix[M];
+            _Pragma("unroll") for (int j = 0; j < M; j++) { v[j] = dg[j]; ix[j] = j; }
+            _Pragma("unroll") for (int k = 0; k < M; k++) {
+                int big = k; double best = v[k];
+                _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool bgr = v[i] > best; best = bgr ? v[i] : best; big = bgr ? i : big; }
+                const double vk = v[k]; const int ik = ix[k]; int ib = ik;
+                _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool hit = (i == big); ib = hit ? ix[i] : ib; v[i] = hit ? vk : v[i]; ix[i] = hit ? ik : ix[i]; }
+                v[k] = best; ix[k] = ib;
+                if (tid == 0) iw[k] = ib;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int pv[M]; int myrank = 0;
+        _Pragma("unroll") for (int k = 0; k < M; k++) { pv[k] = iw[k]; myrank = (pv[k] == me) ? k : myrank; }
+        const int prow = iw[me];
+        // ---- row `me` of the permuted matrix (lower triangle of the input only)
+        double arow[M];
+        _Pragma("unroll") for (int j = 0; j < M; j++) { const int r = prow > pv[j] ? prow : pv[j], c = prow > pv[j] ? pv[j] : prow; arow[j] = A[r + LD * c] + ((j == me) ? diag_add : 0.0); }
+        // ---- left-looking LDL^T
+        double lrow[M], dk[M]; int sign = 0;
+        _Pragma("unroll") for (int k = 0; k < M; k++) {
+            double t = 0.0;
+            _Pragma("unroll") for (int j = 0; j < k; j++) t += lrow[j] * (dk[j] * hs_readlane(lrow[j], k));
+            const double vv = arow[k] - t;
+            const double d = hs_readlane(vv, k);
+            dk[k] = d;
+            lrow[k] = (fabs(d) > 0.0) ? vv / d : vv;
+            if (sign == 1) { if (d < 0) sign = 2; } else if (sign == -1) { if (d > 0) sign = 2; } else { if (d > 0) sign = 1; else if (d < 0) sign = -1; }
+        }
+        if (tid == 0 && !(sign == 1 || sign == 0)) *ok = 0;
+        if (act) { _Pragma("unroll") for (int j = 0; j < M - 1; j++) if (j < me) Lw[me * M + j] = lrow[j]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- column `me` of the inverse: P e_me is the unit vector at position myrank
+        if (act) {
+            double y[M];
+            _Pragma("unroll") for (int k = 0; k < M; k++) {
+                double s = (k == myrank) ? 1.0 : 0.0;
+                _Pragma("unroll") for (int j = 0; j < k; j++) s -= Lw[k * M + j] * y[j];
+                y[k] = s; if (k % 4 == 3) HS_CBAR();
+            }
+            _Pragma("unroll") for (int k = 0; k < M; k++) y[k] = (fabs(dk[k]) > TOL) ? y[k] / dk[k] : 0.0;
+            _Pragma("unroll") for (int k = M - 1; k >= 0; k--) {
+                double s = y[k];
+                _Pragma("unroll") for (int j = k + 1; j < M; j++) s -= Lw[j * M + k] * y[j];
+                y[k] = s; if (k % 4 == 0) HS_CBAR();
+            }
+            _Pragma("unroll") for (int k = 0; k < M; k++) NI[pv[k] + LD * me] = -y[k];
+        }
+    })
 #endif
-    _Pragma("unroll")
-    for (int j = 0; j < N; j++) {
-        HS_WPHASE(if (tid >= j && tid < N) {
-            double sj = CM(A, j, j, LD) + diag_add, st = CM(A, tid, j, LD);
-            _Pragma("unroll")
-            for (int k = 0; k < j; k++) { const double ljk = Lo[j * LD + k]; sj -= ljk * ljk; st -= Lo[tid * LD + k] * ljk; }
-            const bool good = sj > 0.0;
-            const double r = hs_rsqrt(good ? sj : 1.0);
-            if (tid == j) { rd[j] = r; if (!good) *ok = 0; } else Lo[tid * LD + j] = st * r;
-        })
-    }
 }
 // global (dense, ld = rows) <-> LDS (padded ld); threads stride over columns with a fixed row
 template <int NT> HD void ld_mat(int tid, double* dst, int ldd, const double* src, int rows, int cols) {
@@ -232,6 +299,21 @@ HD void sweep_tiles3(SweepLdsT<N, M, PY>& S, int lane) {
     mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0>(lane, td);
 }
 
+// K = (-Quu_inv) Qux : TM x TN tiles dealt round-robin
+template <int W, int N, int M, int PY>
+HD void sweep_tilesK(SweepLdsT<N, M, PY>& S, int lane) {
+    constexpr int LDM = SweepLdsT<N, M, PY>::LDM;
+    constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
+    constexpr int NTL = (TM * TN - W + 3) / 4;
+    if (NTL <= 0) return;
+    MTile td[NTL > 0 ? NTL : 1];
+    _Pragma("unroll") for (int q = 0; q < NTL; q++) {
+        const int t = W + 4 * q;
+        td[q] = MTile{S.K, LDM, nullptr, 0, 16 * (t % TM), 16 * (t / TM), M, N, S.LQ, LDM, S.Qux, LDM, M, false, nullptr, 0, nullptr, 0, 0};
+    }
+    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0>(lane, td);
+}
+
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
 template <int NT, int N, int M, int PY>
 HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
@@ -289,17 +371,9 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         HS_PHASE_L(NT, if (tid < M) gQu[kk * M + tid] = S.Qu[tid];
                    st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
-        // wave 0: Cholesky of (Quu - 1e-9 I) and the inverse (registers, no workgroup barrier); other waves symmetrise Qxx
-        chol_w<M, LDM>(S.Quu, S.LQ, S.rdQ, -1e-9, &SWC.ok);
-        // K = -Quu^-1 Qux and dU = -Quu^-1 Qu by two triangular solves per column (lanes 0..N-1: columns of Qux, lane N: Qu);
-        // the reference forms Quu_inv = LDLT.solve(I) and multiplies (SinglePhase.cpp:375-380): same result to rounding
-        HS_WPHASE(if (tid <= N) {
-            double y[M];
-            _Pragma("unroll") for (int i = 0; i < M; i++) y[i] = (tid < N) ? CM(S.Qux, i, tid, LDM) : S.Qu[i];
-            _Pragma("unroll") for (int i = 0; i < M; i++) { double s = y[i]; _Pragma("unroll") for (int k2 = 0; k2 < i; k2++) s -= S.LQ[i * LDM + k2] * y[k2]; y[i] = s * S.rdQ[i]; if (i % 3 == 2) HS_CBAR(); }
-            _Pragma("unroll") for (int i = M - 1; i >= 0; i--) { double s = y[i]; _Pragma("unroll") for (int k2 = i + 1; k2 < M; k2++) s -= S.LQ[k2 * LDM + i] * y[k2]; y[i] = s * S.rdQ[i]; if (i % 3 == 0) HS_CBAR(); }
-            _Pragma("unroll") for (int i = 0; i < M; i++) { if (tid < N) CM(S.K, i, tid, LDM) = -y[i]; else S.dU[i] = -y[i]; }
-        })
+        // wave 0: Eigen's pivoted LDLT of (Quu - 1e-9 I), positivity test, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:366-375);
+        // meanwhile the other waves symmetrise Qxx (next phase).  Scratch: the HA block (dead since phase 2) and the reduction buffer.
+        ldlt_inverse_w<M, LDM>(S.Quu, -1e-9, S.LQ, S.HA, reinterpret_cast<int*>(S.red), &SWC.ok);
         SW_STAMP(4)
         HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) {
@@ -312,6 +386,12 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         SW_STAMP(5)
         if (!SWC.ok) return false;
         SW_STAMP(6)
+        // K = -Quu_inv Qux on the matrix cores (TM x TN tiles over the waves) ; dU = -Quu_inv Qu on the last lanes   (SinglePhase.cpp:379-380)
+        HS_PHASE_L(NT,
+            { const int w = tid >> 6, lane = tid & 63;
+              switch (w) { case 0: sweep_tilesK<0, N, M, PY>(S, lane); break; case 1: sweep_tilesK<1, N, M, PY>(S, lane); break;
+                           case 2: sweep_tilesK<2, N, M, PY>(S, lane); break; default: sweep_tilesK<3, N, M, PY>(S, lane); } }
+            if (tid >= NT - M) { const int i = tid - (NT - M); double s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; })
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves

@@ -100,6 +100,13 @@ HD void chol_f(const double* A, double* Lo, double* rd, double diag_add) {
     HS_PHASE(NT, chol_r<N, LD>(A, LD, 1, Lo, rd, diag_add, tid);)
 #endif
 }
+// in-place factorisation of a 12x12 matrix by ONE wave (tid = lane): registers + lane broadcasts on the GPU, plain loops in the emulator
+#ifdef HS_HOST_EMU
+#define WB_CHOL_G(G_, rd_, tid_) { if ((tid_) == 0) { for (int j_ = 0; j_ < 12; j_++) { double sj_ = (G_)[j_ * 12 + j_]; for (int k_ = 0; k_ < j_; k_++) sj_ -= (G_)[j_ * 12 + k_] * (G_)[j_ * 12 + k_]; \
+    const double r_ = hs_rsqrt(sj_); (rd_)[j_] = r_; for (int i_ = j_ + 1; i_ < 12; i_++) { double st_ = (G_)[i_ * 12 + j_]; for (int k_ = 0; k_ < j_; k_++) st_ -= (G_)[i_ * 12 + k_] * (G_)[j_ * 12 + k_]; (G_)[i_ * 12 + j_] = st_ * r_; } } } }
+#else
+#define WB_CHOL_G(G_, rd_, tid_) chol_r<12, 12>((G_), 12, 1, (G_), (rd_), 0.0, (tid_))
+#endif
 #ifndef HS_SOLVE_CBAR
 #define HS_SOLVE_CBAR 100    // rows of a triangular solve between two scheduling fences (100: none; 1 keeps every row's loads behind the previous row)
 #endif
@@ -341,9 +348,11 @@ HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bo
     }
     bwd_s<18, 18>(L.M, L.rdM, top);
 }
-// keep the Schur factor of wb_kkt_direct: GG is about to receive the foot tangents
+// Schur factor for the derivative columns: Pinocchio's computeKKTContactDynamicMatrixInverse runs with damping 0 (WBM.cpp:467), unlike
+// the forward solve (1e-12, WBM.cpp:411): G = X^T X is factored once more without the damping, into LDS that survives the tangent pass
+// (GG is about to receive the foot tangents).  wb_kkt_direct leaves G in L.G().
 template <int NT> HD void wb_keep_schur(WbCore& L, WbDeriv& D) {
-    HS_PHASE(NT, for (int i = tid; i < 144; i += NT) D.LGs[i] = L.LG()[i]; if (tid < 12) D.rdGs[tid] = L.rdG[tid];)
+    chol_f<NT, 12, 12>(L.G(), D.LGs, D.rdGs, 0.0);
 }
 
 // Tangent pass.  SEEDS (the W column / foot-tangent column a result goes to): 0..35: d ID(q,v,acc)/dx_seed (psi_dyn, gravity `grav`);
@@ -354,7 +363,7 @@ template <int NT> HD void wb_keep_schur(WbCore& L, WbDeriv& D) {
 //     trunk's own inertial force rides with leg 0) as partial sums, added in leg order and walked back through the base joints afterwards;
 //   * a seed on the base position moves nothing that is stored (only foot positions depend on it): zeros.
 template <int NT>
-HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double vscale_dyn, double vscale_kin, double ascale_kin, bool q_only) {
+HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double vscale_dyn, double vscale_kin, double ascale_kin, bool q_only, bool chol_g = false) {
     // base seeds, q first so that q_only drops the tail: dyn q3..5 | kin q3..5 | dyn v0..5
     auto base_seed = [](int bs) { return bs < 3 ? 3 + bs : bs < 6 ? 36 + bs : 12 + bs; };
     // round A: the 60 DYNAMIC tasks (base q3..5 and v0..5 seeds x 4 legs, leg-joint q and v seeds); round B: the 24 KINEMATIC tasks
@@ -390,7 +399,9 @@ HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double 
         }
         // base-position seeds (0..2 and 36..38): zero columns
         for (int e = tid; e < 108; e += NT) { const int sd = e / 18, i = e % 18; D.W[i * WT + (sd < 3 ? sd : 33 + sd)] = 0.0; }
-        for (int e = tid; e < 36; e += NT) { const int j = e / 12, r = e % 12; L.dacc()[r * 18 + j] = 0.0; L.dvel()[r * 18 + j] = 0.0; })
+        for (int e = tid; e < 36; e += NT) { const int j = e / 12, r = e % 12; L.dacc()[r * 18 + j] = 0.0; L.dvel()[r * 18 + j] = 0.0; }
+        // two-wave LQ knot: wave 1 (done with the shorter round) factors the Gram matrix the cache delivered, for the column solves
+        if (NT >= 128 && chol_g && tid >= 64) WB_CHOL_G(D.LGs, D.rdGs, tid - 64);)
     HS_PHASE(NT, if (tid < (q_only ? 6 : 12)) {
         const int seed = base_seed(tid), tq = seed < 18 ? seed : seed >= 36 ? seed - 36 : -1;
         V3<Dual> fb = {Dual(0.0), Dual(0.0), Dual(0.0)}, nb = fb;
@@ -502,9 +513,9 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
             store_image<NT, 324, 324>(kc + KC_M, tid, [&](int e, int, int) { return L.M[e]; });
             store_image<NT, 216, 216>(kc + KC_X, tid, [&](int e, int, int) { return L.Xm()[e]; });
             store_image<NT, 216, 216>(kc + KC_J, tid, [&](int e, int, int) { return L.Jall[e]; });
-            store_image<NT, 144, 144>(kc + KC_LG, tid, [&](int e, int, int) { return L.LG()[e]; });
+            store_image<NT, 144, 144>(kc + KC_LG, tid, [&](int e, int, int) { return L.G()[e]; });       // the Gram matrix itself: the LQ knot factors it WITHOUT the damping
             if (tid < 18) { kc[KC_RDM + tid] = L.rdM[tid]; kc[KC_QDD + tid] = L.qdd[tid]; }
-            if (tid < 12) { kc[KC_RDG + tid] = L.rdG[tid]; kc[KC_GRF + tid] = L.grf[tid]; kc[KC_LAM + tid] = L.lam[tid]; kc[KC_FP + tid] = L.fpos[tid]; kc[KC_FV + tid] = L.fvel[tid]; })
+            if (tid < 12) { kc[KC_GRF + tid] = L.grf[tid]; kc[KC_LAM + tid] = L.lam[tid]; kc[KC_FP + tid] = L.fpos[tid]; kc[KC_FV + tid] = L.fvel[tid]; })
     }
     RL_STAMP(3)
     // integrate, defect of knot k+1 (and of knot 0 for the very first knot of phase 0), constraint values + barrier, cost terms:
@@ -815,12 +826,15 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
             _Pragma("unroll") for (int q = 0; q < KC_SIZE / NT; q++) {
                 const int i = q * NT + tid; const double v = r[q];
                 KC_REGION(KC_M, KC_X, L.M) KC_REGION(KC_X, KC_LG, L.Xm()) KC_REGION(KC_LG, KC_RDM, D.LGs) KC_REGION(KC_RDM, KC_RDG, L.rdM)
-                KC_REGION(KC_RDG, KC_QDD, D.rdGs) KC_REGION(KC_QDD, KC_GRF, L.qdd) KC_REGION(KC_GRF, KC_LAM, L.grf) KC_REGION(KC_LAM, KC_J, L.lam)
+                KC_REGION(KC_QDD, KC_GRF, L.qdd) KC_REGION(KC_GRF, KC_LAM, L.grf) KC_REGION(KC_LAM, KC_J, L.lam)
                 KC_REGION(KC_J, KC_FP, L.Jall) KC_REGION(KC_FP, KC_FV, L.fpos) KC_REGION(KC_FV, KC_FV + 12, L.fvel)
             }
         })
     LQ_STAMP(11)
     if (cached) {
+        // the cache holds the Gram matrix G = X^T X: its factor WITHOUT the damping of the forward solve (see wb_keep_schur); in the two-wave
+        // knot this runs on wave 1 behind its tangent round, the shorter one (wb_dpass, chol_g)
+        if (NT < 128) chol_f<NT, 12, 12>(D.LGs, D.LGs, D.rdGs, 0.0);
         LQ_STAMP(0)
     } else {
         HS_PHASE(NT, if (tid < 12) L.tau[6 + tid] = L.u[tid];)
@@ -832,7 +846,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     LQ_STAMP(1)
     const int m = 3 * P.nc;
     HS_PHASE(NT, if (tid < 18) L.acc[tid] = L.qdd[tid]; if (tid < 12) L.fext[tid] = L.grf[tid];)
-    wb_dpass<NT>(L, D, md, GRAV, 1.0, 1.0, 1.0, false);
+    wb_dpass<NT>(L, D, md, GRAV, 1.0, 1.0, 1.0, false, cached);
     LQ_STAMP(2)
     if (NT >= 128) {
         // ---- two waves, two jobs, no workgroup barrier in between (disjoint LDS): wave 0 solves the 48 KKT columns and copies A, B, C, D

@@ -315,6 +315,25 @@ def barrel_roll_problem(switching_times=(0.0, 0.12, 0.33, 0.75, 0.90, 1.10, 1.25
     for _ in range(repeat - 1):   # flight -> landing pairs appended with the same durations
         for j in (4, 5):
             sw.append(sw[-1] + (switching_times[j + 1] - switching_times[j])); cts.append(contacts[j]); tgt.append(xf[j]); wts.append(_BR_WEIGHTS[j])
+    return _br_build(sw, cts, tgt, wts, xinit, dt), xinit
+
+
+def barrel_roll_running_problem(knots=(12, 21, 42, 15, 20, 15, 100, 125), dt=0.01):
+    """BASELINE config 4 as SURVEY 8(d) specifies it: the barrel-roll schedule of BarrelRollTO.cpp:70-81 with a running lead-out,
+    1111(12) 0101(21) 0000(42) 1111(15) 0000(20) 1111(15) 0101(100) 1010(125) = 8 hybrid phases / 350 knots; tracking targets and
+    weights of the six shipped sets (BarrelRoll/setting/br_cost_weights.JSON, BarrelRollTO.cpp:277-338), the last set reused for the
+    two running phases; constraints and initial guess as in barrel_roll_problem.  Returns (phases, xinit)."""
+    xinit, xf = barrel_roll_states()
+    cts = [(1, 1, 1, 1), (0, 1, 0, 1), (0, 0, 0, 0), (1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 1, 1), (0, 1, 0, 1), (1, 0, 1, 0)]
+    assert len(knots) == len(cts)
+    sw = [0.0]
+    for h in knots:
+        sw.append(sw[-1] + h * dt)
+    idx = [0, 1, 2, 3, 4, 5, 5, 5]
+    return _br_build(sw, cts, [xf[i] for i in idx], [_BR_WEIGHTS[i] for i in idx], xinit, dt), xinit
+
+
+def _br_build(sw, cts, tgt, wts, xinit, dt):
     nph = len(cts)
     phases = []
     for i in range(nph):
@@ -345,7 +364,7 @@ def barrel_roll_problem(switching_times=(0.0, 0.12, 0.33, 0.75, 0.90, 1.10, 1.25
             t = np.float32(t + np.float32(dt))
         ph["Xbar"] = X
         phases.append(ph)
-    return phases, xinit
+    return phases
 
 
 def br_ddp_setting(**kw):

@@ -147,7 +147,7 @@ struct Solver {
             PhaseDef& P = ph[i]; P.d = phases[i];
             model_dims(P.d.model, P.n, P.m, P.p); P.h = P.d.horizon;
             int h1 = P.h + 1;
-            auto cp = [&](const double* src, int w, std::vector<double>& dst) { dst.assign((size_t)h1 * w, 0.0); if (src && w) std::memcpy(dst.data(), src, sizeof(double) * h1 * w); };
+            auto cp = [&](const auto* src, int w, std::vector<double>& dst) { dst.assign((size_t)h1 * w, 0.0); if (src && w) std::copy(src, src + (size_t)h1 * w, dst.begin()); };   // (element-wise: the ABI side is always fp64, see ORC_LONG_DOUBLE)
             cp(P.d.xr, P.n, P.xr); cp(P.d.ur, P.m, P.ur); cp(P.d.yr, P.p, P.yr);
             cp(P.d.foot_pos, 12, P.foot_pos); cp(P.d.foot_vel, 12, P.foot_vel); cp(P.d.body_pos, 3, P.body_pos);
             P.ref_contact.assign((size_t)h1 * 4, 0);
@@ -359,7 +359,7 @@ struct Solver {
                 std::vector<double> tx(n, 0.0), txx((size_t)n * n, 0.0);
                 for (int f = 0; f < 4; f++) {
                     if (pass < 2) {
-                        const double* w = pass == 0 ? P.d.w_foot_reg : P.d.w_swing_pos;
+                        const auto* w = pass == 0 ? P.d.w_foot_reg : P.d.w_swing_pos;
                         bool on = (pass == 0 ? rc[f] > 0 : rc[f] == 0) && w[0] >= 0;
                         if (!on) continue;
                         double d[3]; for (int a = 0; a < 3; a++) d[a] = (F.pos[f][a] - x[a]) - (fp[3 * f + a] - bp[a]);
@@ -367,7 +367,7 @@ struct Solver {
                         for (int i = 0; i < 18; i++) { double s = 0; for (int a = 0; a < 3; a++) s += J[a][i] * w[a] * d[a]; tx[i] += s * dt; }
                         for (int j = 0; j < 18; j++) for (int i = 0; i < 18; i++) { double s = 0; for (int a = 0; a < 3; a++) s += J[a][i] * w[a] * J[a][j]; txx[i + n * j] += s * dt; }
                     } else {
-                        const double* w = P.d.w_swing_vel;
+                        const auto* w = P.d.w_swing_vel;
                         if (!(rc[f] == 0 && w[0] >= 0)) continue;
                         double dv[3]; for (int a = 0; a < 3; a++) dv[a] = F.vel[f][a] - P.foot_vel[(size_t)k * 12 + 3 * f + a];
                         double J[3][36]; for (int a = 0; a < 3; a++) for (int j = 0; j < 18; j++) { J[a][j] = F.Jv[f][a][j]; J[a][18 + j] = F.J[f][a][j]; }
@@ -443,7 +443,7 @@ struct Solver {
         {   // WBFootPlaceReg::terminal_cost_par (MHPCCost.cpp:90-117): x2
             std::vector<double> tx(n, 0.0), txx((size_t)n * n, 0.0);
             for (int f = 0; f < 4; f++) if (rc[f] > 0 && P.d.w_foot_reg[0] >= 0) {
-                const double* w = P.d.w_foot_reg; double d[3]; for (int a = 0; a < 3; a++) d[a] = (F.pos[f][a] - x[a]) - (fp[3 * f + a] - bp[a]);
+                const auto* w = P.d.w_foot_reg; double d[3]; for (int a = 0; a < 3; a++) d[a] = (F.pos[f][a] - x[a]) - (fp[3 * f + a] - bp[a]);
                 double J[3][18]; for (int a = 0; a < 3; a++) for (int j = 0; j < 18; j++) J[a][j] = j < 3 ? 0.0 : F.J[f][a][j];
                 for (int i = 0; i < 18; i++) { double s = 0; for (int a = 0; a < 3; a++) s += J[a][i] * w[a] * d[a]; tx[i] += 2 * s; }
                 for (int j = 0; j < 18; j++) for (int i = 0; i < 18; i++) { double s = 0; for (int a = 0; a < 3; a++) s += J[a][i] * w[a] * J[a][j]; txx[i + n * j] += 2 * s; }
@@ -642,7 +642,7 @@ struct Solver {
             iter++;
             success = backward_sweep(q, reg);
             if (success) break;
-            reg = std::max(reg * opt.update_regularization, 1e-03);
+            reg = std::max<double>(reg * opt.update_regularization, 1e-03);
             if (reg > 1e2) break;
         }
         reg = reg / 20; if (reg < 1e-06) reg = 0;
@@ -683,7 +683,7 @@ struct Solver {
         for (size_t i = 0; i < ph.size(); i++) { Traj& T = q.tr[i];
             for (size_t c = 0; c < T.th.size(); c++) {
                 if (std::fabs(T.th[c]) < opt.tconstr_thresh) continue;
-                if (std::fabs(T.th[c]) > 0.005) { T.sigma[c] *= opt.update_penalty; T.sigma[c] = std::min(T.sigma[c], ph[i].d.al_td.sigma_max); }
+                if (std::fabs(T.th[c]) > 0.005) { T.sigma[c] *= opt.update_penalty; T.sigma[c] = std::min<double>(T.sigma[c], ph[i].d.al_td.sigma_max); }
                 else T.lambda[c] += T.th[c] * T.sigma[c];
             } }
     }

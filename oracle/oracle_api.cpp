@@ -1,8 +1,27 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C-ABI of the CPU restatement: the same hsddp_* entry points
 // as include/hsddp.h (so parity tests drive both backends with one harness) plus model-level
 // oracle_* probes used to pin the restatement against the reference's golden vectors.
-#include "hsddp_oracle.hpp"
+//
+// -DORC_LONG_DOUBLE builds the SAME restatement with every internal scalar an 80-bit long double (liboracle_hsddp_ld.so): the
+// "exact" side of the conditioning tests (tests/test_gpu_parity.py): where fp64 implementations of the same algebra differ by
+// more than north_star's 1e-6 on K, it says which of them is nearer the true iterate.  The ABI stays fp64 on both builds.
+#include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <limits>
+#include <cstdlib>
 #include <new>
+#include <omp.h>
+#include "hsddp.h"
+typedef double abi_f64;
+#ifdef ORC_LONG_DOUBLE
+#define double long double
+#define orc orc_ld      // both libraries may be loaded into one process: keep their (weak, inline) C++ symbols apart
+#endif
+#include "hsddp_oracle.hpp"
 
 struct hsddp_handle { orc::Solver s; };
 using namespace orc;
@@ -26,20 +45,20 @@ int oracle_set_threads(hsddp_handle_t* h, int lq_threads, int problem_threads) {
     h->s.lq_threads = lq_threads > 0 ? lq_threads : 1; h->s.problem_threads = problem_threads > 0 ? problem_threads : 1; return 0;
 }
 
-int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) {
+int hsddp_set_initial_condition(hsddp_handle_t* h, const abi_f64* x0) {
     if (!h || !x0) return HSDDP_EINVAL;
     int n0 = h->s.ph[0].n;
-    for (int b = 0; b < h->s.batch; b++) { std::memset(h->s.pb[b].x0, 0, sizeof(h->s.pb[b].x0)); std::memcpy(h->s.pb[b].x0, x0 + (size_t)b * n0, sizeof(double) * n0); }
+    for (int b = 0; b < h->s.batch; b++) { std::memset(h->s.pb[b].x0, 0, sizeof(h->s.pb[b].x0)); std::copy(x0 + (size_t)b * n0, x0 + (size_t)(b + 1) * n0, h->s.pb[b].x0); }
     return HSDDP_OK;
 }
-int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per_problem) {
+int hsddp_set_nominal(hsddp_handle_t* h, int phase, const abi_f64* Xbar, const abi_f64* Ubar, int per_problem) {
     if (!h || phase < 0 || phase >= (int)h->s.ph.size()) return HSDDP_EINVAL;
     const PhaseDef& P = h->s.ph[phase]; size_t sx = (size_t)(P.h + 1) * P.n, su = (size_t)P.h * P.m;
     for (int b = 0; b < h->s.batch; b++) {
         Traj& T = h->s.pb[b].tr[phase];
-        if (Xbar) { const double* s = Xbar + (per_problem ? b * sx : 0); std::copy(s, s + sx, T.Xbar.begin()); std::copy(s, s + sx, T.X.begin()); }
-        if (Ubar) { const double* s = Ubar + (per_problem ? b * su : 0); std::copy(s, s + su, T.Ubar.begin()); std::copy(s, s + su, T.U.begin()); }
-        std::fill(T.K.begin(), T.K.end(), 0.0); std::fill(T.dU.begin(), T.dU.end(), 0.0); std::fill(T.dX.begin(), T.dX.end(), 0.0);
+        if (Xbar) { const abi_f64* s = Xbar + (per_problem ? b * sx : 0); std::copy(s, s + sx, T.Xbar.begin()); std::copy(s, s + sx, T.X.begin()); }
+        if (Ubar) { const abi_f64* s = Ubar + (per_problem ? b * su : 0); std::copy(s, s + su, T.Ubar.begin()); std::copy(s, s + su, T.U.begin()); }
+        for (auto& v : T.K) v = 0; for (auto& v : T.dU) v = 0; for (auto& v : T.dX) v = 0;
     }
     return HSDDP_OK;
 }
@@ -47,19 +66,19 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
     if (!h || !opt) return HSDDP_EINVAL;
     h->s.solve(*opt, max_cputime_ms); return HSDDP_OK;
 }
-int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.hybrid_rollout(q, eps, *opt); return 0; }
+int hsddp_hybrid_rollout(hsddp_handle_t* h, abi_f64 eps, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.hybrid_rollout(q, eps, *opt); return 0; }
 int hsddp_compute_cost(hsddp_handle_t* h, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.compute_cost(q, *opt); return 0; }
 int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) { for (auto& q : h->s.pb) h->s.LQ_approximation(q, *opt); return 0; }
-int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
+int hsddp_backward_sweep(hsddp_handle_t* h, abi_f64 reg, int* success) {
     for (int b = 0; b < h->s.batch; b++) { bool ok = h->s.backward_sweep(h->s.pb[b], reg); if (success) success[b] = ok; }
     return 0;
 }
-int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) { (void)opt; for (auto& q : h->s.pb) h->s.linear_rollout(q, eps); return 0; }
+int hsddp_linear_rollout(hsddp_handle_t* h, abi_f64 eps, const hsddp_option_t* opt) { (void)opt; for (auto& q : h->s.pb) h->s.linear_rollout(q, eps); return 0; }
 int hsddp_update_nominal_trajectory(hsddp_handle_t* h) { for (auto& q : h->s.pb) h->s.update_nominal_trajectory(q); return 0; }
-int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* dV_1, double* dV_2) {
+int hsddp_get_exp_cost_change(hsddp_handle_t* h, abi_f64* dV_1, abi_f64* dV_2) {
     for (int b = 0; b < h->s.batch; b++) { dV_1[b] = h->s.pb[b].dV_1; dV_2[b] = h->s.pb[b].dV_2; } return 0;
 }
-int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* feas) { for (int b = 0; b < h->s.batch; b++) feas[b] = h->s.measure_dynamics_feasibility(h->s.pb[b]); return 0; }
+int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, abi_f64* feas) { for (int b = 0; b < h->s.batch; b++) feas[b] = h->s.measure_dynamics_feasibility(h->s.pb[b]); return 0; }
 
 int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) {
     for (int b = 0; b < h->s.batch; b++) {
@@ -111,14 +130,14 @@ int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* 
     if (!h || phase < 0 || phase >= (int)h->s.ph.size() || field < 0 || field >= HSDDP_F_COUNT) return HSDDP_EINVAL;
     field_ptr(h->s.ph[phase], h->s.pb[0].tr[phase], field, *count, *elems); return 0;
 }
-int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
+int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, abi_f64* dst) {
     if (!h || phase < 0 || phase >= (int)h->s.ph.size() || field < 0 || field >= HSDDP_F_COUNT || b0 < 0 || b0 + nb > h->s.batch) return HSDDP_EINVAL;
     for (int b = 0; b < nb; b++) {
         int count, elems; const Traj& T = h->s.pb[b0 + b].tr[phase];
         const std::vector<double>* v = field_ptr(h->s.ph[phase], T, field, count, elems);
         size_t sz = (size_t)count * elems;
         if (field == HSDDP_F_PHI) dst[b] = T.Phi;
-        else if (v) std::memcpy(dst + b * sz, v->data(), sizeof(double) * sz);
+        else if (v) std::copy(v->begin(), v->begin() + sz, dst + b * sz);
     }
     return 0;
 }
@@ -133,20 +152,20 @@ int hsddp_warm_start_phase(hsddp_handle_t* dst, int dphase, hsddp_handle_t* src,
         Traj& D = dst->s.pb[b].tr[dphase];
         const Traj* S = has ? &src->s.pb[b].tr[sphase] : nullptr; const int hs = has ? src->s.ph[sphase].h : 0;
         for (int k = 0; k <= hd; k++) for (int i = 0; i < n; i++) {
-            const int ks = k + shift; double v = 0.0;
+            const int ks = k + shift; abi_f64 v = 0.0;
             if (has) v = (ks <= hs) ? S->Xbar[(size_t)ks * n + i] : S->X[(size_t)hs * n + i];
             D.Xbar[(size_t)k * n + i] = v; D.X[(size_t)k * n + i] = v; D.dX[(size_t)k * n + i] = 0.0;
         }
         for (int k = 0; k < hd; k++) {
             const int ks = k + shift; const bool cs = has && ks < hs;
-            for (int i = 0; i < m; i++) { const double v = cs ? S->Ubar[(size_t)ks * m + i] : 0.0; D.Ubar[(size_t)k * m + i] = v; D.U[(size_t)k * m + i] = v; D.dU[(size_t)k * m + i] = 0.0; }
+            for (int i = 0; i < m; i++) { const abi_f64 v = cs ? S->Ubar[(size_t)ks * m + i] : 0.0; D.Ubar[(size_t)k * m + i] = v; D.U[(size_t)k * m + i] = v; D.dU[(size_t)k * m + i] = 0.0; }
             for (int i = 0; i < m * n; i++) D.K[(size_t)k * m * n + i] = cs ? S->K[(size_t)ks * m * n + i] : 0.0;
         }
     }
     return 0;
 }
 // MHPCLocomotion::publish_mpc_cmd (MHPC/MHPCLocomotion.cpp:190-287) restated: field order of MHPC_Command_lcmt.lcm, fp32 casts
-int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double mpc_time, double dt, const float* status_times, unsigned int* out) {
+int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, abi_f64 mpc_time, abi_f64 dt, const float* status_times, unsigned int* out) {
     if (!h || problem < 0 || problem >= h->s.batch || n_steps <= 0 || !out) return HSDDP_EINVAL;
     std::vector<std::pair<int, int>> idx;
     for (int i = 0; i < (int)h->s.ph.size() && (int)idx.size() < n_steps; i++) {
@@ -154,7 +173,7 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double
         for (int k = 0; k < h->s.ph[i].h && (int)idx.size() < n_steps; k++) idx.push_back({i, k});
     }
     if ((int)idx.size() < n_steps) return HSDDP_EINVAL;
-    auto putf = [](unsigned int* p, double v) { float f = (float)v; std::memcpy(p, &f, 4); };
+    auto putf = [](unsigned int* p, abi_f64 v) { float f = (float)v; std::memcpy(p, &f, 4); };
     out[0] = (unsigned int)n_steps; unsigned int* p = out + 1;
     const Problem& pb = h->s.pb[problem];
     auto rows = [&](int w, auto get) { for (int s = 0; s < n_steps; s++) for (int e = 0; e < w; e++) get(p++, s, e); };
@@ -171,8 +190,9 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double
     rows(4, [&](unsigned int* q, int s, int e) { float f = status_times ? status_times[idx[s].first * 4 + e] : 0.f; std::memcpy(q, &f, 4); });
     return 0;
 }
-int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
+int hsddp_get_kernel_times(hsddp_handle_t*, int, abi_f64*, long long*, char*, int) { return 0; }
 
+#ifndef ORC_LONG_DOUBLE
 // ---------------------------------------------------------------- model-level probes (tests only)
 // continuous-time WB contact dynamics: qdd(18), grf(12)   (WBM.cpp:38-57 / testKKTDynamics.cpp:97-121)
 void oracle_wb_forward(const double* x, const double* u, const int* contact, double psi_dyn, double alpha, double* qdd, double* grf) {
@@ -234,4 +254,5 @@ void oracle_hkd_reset(const double* x, const int* c, const int* cn, double psi, 
     if (Px) hkd_resetmap_partial(x, c, cn, psi, Px);
 }
 
+#endif
 }  // extern "C"

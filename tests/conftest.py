@@ -27,6 +27,15 @@ def oracle_lib():
 
 
 @pytest.fixture(scope="session")
+def oracle_ld_lib():
+    """oracle/liboracle_hsddp_ld.so — the same restatement with 80-bit long double internals: arbiter of the conditioning-limited cases."""
+    path = os.path.join(ROOT, "oracle", "liboracle_hsddp_ld.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return pkg._abi.bind(ctypes.CDLL(path))
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     return pkg.load_hip_library()
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU-box session: tests, bench at the driver's command, in-kernel stamps (diagnostic builds).  Usage: tools/gpu_session.sh <tag> [steps...]
+set -o pipefail
+TAG=${1:-s}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+for step in "$@"; do
+  case $step in
+    tests) timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "tests rc=$?" | tee -a $OUT/summary.txt; tail -5 $OUT/tests.log ;;
+    bench20) timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $OUT/bench20.json 2> $OUT/bench20.err; echo "bench20 rc=$?" | tee -a $OUT/summary.txt; cut -c1-1500 $OUT/bench20.json ;;
+    bench10) timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 > $OUT/bench10.json 2> $OUT/bench10.err; echo "bench10 rc=$?" | tee -a $OUT/summary.txt; cut -c1-1500 $OUT/bench10.json ;;
+    bench5) timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench5.json 2> $OUT/bench5.err; echo "bench5 rc=$?" | tee -a $OUT/summary.txt; cut -c1-1500 $OUT/bench5.json ;;
+    micro) timeout -k 10 300 python3 tools/microbench.py > $OUT/micro.log 2>&1; echo "micro rc=$?" | tee -a $OUT/summary.txt; cat $OUT/micro.log ;;
+    rollprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DROLL_PROF" > $OUT/build_rollprof.log 2>&1 && ROLL_PROF=1 timeout -k 10 300 python3 tools/microbench.py > $OUT/rollprof.log 2>&1; echo "rollprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/rollprof.log ;;
+    swprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DSW_PROF" > $OUT/build_swprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/swprof.log 2>&1; echo "swprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/swprof.log ;;
+    lqprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DLQ_PROF" > $OUT/build_lqprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/lqprof.log 2>&1; echo "lqprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/lqprof.log ;;
+    rebuild) make -C cafe-mpc_amd/csrc clean all > $OUT/build.log 2>&1; echo "rebuild rc=$?" | tee -a $OUT/summary.txt ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
