@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — DDP iterations/sec of the batched HS-DDP solve (BASELINE.json metric) on N MI355X GPUs.
+"""bench.py — DDP iterations/sec of the batched HS-DDP solve (BASELINE.json metric) on N MI355X GPUs of one node.
 
-Workload (config.workload): BASELINE.json configs[2] — Mini-Cheetah whole-body, N=200 knots as 4 contact phases
-(1111 -> 0110 -> 1001 -> 0110, dt=0.01), batch of 4096 initial states PER GPU (weak scaling), synthetic inputs
-(SURVEY 8d), fixed-work mode: max_AL_iter=1, cost_thresh=0 so that every problem runs exactly `--steps` DDP
-iterations.  A "step" = one DDP iteration (cost, LQ approximation, regularised Riccati sweep, linear rollout,
-line search, nominal update: MultiPhaseDDP.cpp:277-387) of the whole batch.  Inputs are resident in HBM before
-the timed region.  One process per GPU; the only collective is the RCCL all-gather of the per-problem results.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--strong]
+
+Workload (config.workload), weak scaling (default): BASELINE.json configs[2] — Mini-Cheetah whole-body, N=200 knots as 4 contact
+phases (1111 -> 0110 -> 1001 -> 0110, dt=0.01), an ensemble of 4096 initial states PER GPU, synthetic inputs,
+fixed-work mode: max_AL_iter=1, cost_thresh=0, so every problem runs exactly `--steps` DDP iterations (10).
+`--strong`: BASELINE.json configs[3] — the running barrel roll, 8 hybrid phases / 350 knots, 8192 problems IN TOTAL split over the
+ranks (8192/8 = 1024 per GPU at N=8).
+A "step" = one DDP iteration (cost, LQ approximation, regularised Riccati sweep, linear rollout, line search, nominal update:
+MultiPhaseDDP.cpp:277-387) of the whole batch.  Inputs are resident in HBM before the timed region.  One process per GPU; the only
+collective is the RCCL all-gather of the per-problem results (cafe-mpc_amd/launch.py).  Started without a launcher, `--gpus N`
+starts its own N ranks (before touching the GPU) and fails loudly if the node has fewer GPUs.
 """
 import argparse
 import ctypes
@@ -26,12 +31,15 @@ ALG_BYTES = {
     "k_lq": (150 + 4381) * 8,               # K2: read x,u,y,refs; write A,B,C,D + RCostData
     "k_sweep": (4417 + 1068 + 4128 + 36) * 8,   # K3 Riccati + K4 linear rollout (one fused launch)
     "k_rollout": (528 + 133 + 69) * 8,      # K1 per line-search trial
+    "k_ls_probe": (528 + 133 + 69) * 8,     # K1 per candidate step of a batched line-search launch
 }
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC = "DDP iterations/sec, Mini-Cheetah WB N=200, batch=4096; 1/2/4/8 GPU"
 
 
-def cpu_baseline(pkg, phases_fn, seed, seconds_hint=20.0):
-    """Oracle (CPU restatement of the reference) on this box's host cores — reported baseline, not the target."""
+def cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, steps, nprob=64):
+    """Oracle (CPU restatement of the reference) on this box's host cores, SAME workload and SAME number of DDP iterations per
+    problem as the GPU run, on a bounded sample of the ensemble — reported baseline, not the target."""
     path = os.path.join(ROOT, "oracle", "liboracle_hsddp.so")
     if not os.path.exists(path):
         return None
@@ -39,52 +47,92 @@ def cpu_baseline(pkg, phases_fn, seed, seconds_hint=20.0):
     lib.oracle_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     # the GPU box exposes every host CPU in the affinity mask but a one-GPU job owns a 16-core share: size the pool to that
     cores = min(len(os.sched_getaffinity(0)), 16)
-    K = 2
     phases = phases_fn()
-    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=K, cost_thresh=0.0)
+    opt = opt_fn(steps)
     out = {}
-    for kind, nprob, lq_thr, pb_thr in (("all_cores", max(cores, 1), 1, cores), ("reference_shaped_4thr", 2, 4, 1)):
-        s = pkg.Solver(lib, phases, batch=nprob)
+    for kind, n, lq_thr, pb_thr in (("all_cores", nprob, 1, cores), ("reference_shaped_4thr", 2, 4, 1)):
+        s = pkg.Solver(lib, phases, batch=n)
         for i, p in enumerate(phases):
             s.set_nominal(i, p["Xbar"], p["Ubar"])
-        s.set_initial_condition(pkg.problems.wb_ensemble_x0(nprob, seed))
+        s.set_initial_condition(x0_fn(n))
         lib.oracle_set_threads(s.h, lq_thr, pb_thr)
         t0 = time.time(); s.solve(opt); dt = time.time() - t0
-        out[kind] = nprob * K / dt
+        info = s.info_arrays()
+        out[kind] = (float(info["n_iters"].sum()) / dt, float(info["n_ls_iters"].sum()) / max(float(info["n_iters"].sum()), 1.0), dt)
         s.close()
-    return {"value": out["all_cores"], "unit": "DDP iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{max(cores,1)} problems x {K} iterations of the same WB N=200 workload, one problem per core "
-                      f"({cores} threads); reference-shaped run (1 problem at a time, 4 OpenMP threads over knots in "
-                      f"LQ_approximation only): {out['reference_shaped_4thr']:.3f} it/s"}
+    return {"value": out["all_cores"][0], "unit": "DDP iterations/s", "cores": cores, "kind": "port",
+            "mean_ls_trials_per_iter": out["all_cores"][1], "seconds": round(out["all_cores"][2], 2),
+            "sample": f"the first {nprob} problems of the same ensemble x {steps} iterations each (same options as the GPU run), one problem "
+                      f"per core on {cores} threads; reference-shaped run (1 problem at a time, 4 OpenMP threads over knots in "
+                      f"LQ_approximation only, 2 problems): {out['reference_shaped_4thr'][0]:.3f} it/s"}
+
+
+def latency_probe(pkg, steps):
+    """BASELINE config 2 (batch 1, N=200): ms per DDP iteration of ONE problem — the latency side of the same kernels."""
+    phases = pkg.problems.wb_trot_problem()
+    s = pkg.MultiPhaseDDP(phases, batch=1)
+    s.set_initial_condition(pkg.problems.wb_ensemble_x0(1, 20241220 + 2))
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0)
+    s.solve(opt)                                           # warm-up (module load, first launches)
+    s2 = pkg.MultiPhaseDDP(phases, batch=1)
+    s2.set_initial_condition(pkg.problems.wb_ensemble_x0(1, 20241220 + 2))
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=steps, cost_thresh=0.0)
+    t0 = time.perf_counter(); s2.solve(opt); dt = time.perf_counter() - t0
+    info = s2.info_arrays()
+    out = {"config": "WB N=200 (4 x 50), batch 1", "ms_per_ddp_iteration": dt * 1e3 / max(int(info["n_iters"][0]), 1),
+           "ls_trials_per_iter": float(info["n_ls_iters"][0]) / max(int(info["n_iters"][0]), 1)}
+    s.close(); s2.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (weak, default 4096) / in total (--strong, default 8192)")
+    ap.add_argument("--strong", action="store_true", help="fixed total work: config 4 (barrel roll, 8 phases, N=350), 8192 problems split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     pkg = ge.load_package()
-    seed = 20241220 + 3
-    B = args.batch
-    x0 = pkg.problems.wb_ensemble_x0(B, seed, first=rank * B)
+    launch = pkg.launch
+    rc = launch.maybe_spawn(args.gpus, os.path.abspath(__file__), sys.argv[1:])      # before anything touches the GPU
+    if rc is not None:
+        sys.exit(rc)
+    import torch
+    rank, world, local, dist = launch.init_ranks("nccl")
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but {world} rank(s) are running", file=sys.stderr); sys.exit(2)
+    dev = f"cuda:{local}"
+
+    if args.strong:
+        total = args.batch or 8192
+        first, B = launch.shard(total, world, rank)
+        seed = 20241220 + 4
+        phases_fn = lambda: pkg.problems.barrel_roll_running_problem()[0]   # noqa: E731
+        xinit = pkg.problems.barrel_roll_running_problem()[1]
+
+        x0_fn = lambda n, first=0: pkg.problems.barrel_roll_ensemble_x0(n, seed, xinit, first=first)   # noqa: E731
+        opt_fn = lambda k: pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=k, cost_thresh=0.0)   # noqa: E731
+        workload = ("barrel roll with running lead-out, WB 36/12/12, 8 hybrid phases / N=350: 1111(12) 0101(21) 0000(42) 1111(15) 0000(20) "
+                    "1111(15) 0101(100) 1010(125), dt=0.01, zero-torque start, ensemble of initial joint poses, fixed-work mode")
+    else:
+        B = args.batch or 4096
+        total = B * world; first = rank * B
+        seed = 20241220 + 3
+        phases_fn = pkg.problems.wb_trot_problem
+        x0_fn = lambda n, first=0: pkg.problems.wb_ensemble_x0(n, seed, first=first)   # noqa: E731
+        opt_fn = lambda k: pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=k, cost_thresh=0.0)   # noqa: E731
+        workload = ("WB 36/12/12, N=200 = 4 contact phases x 50 knots (1111,0110,1001,0110), dt=0.01, ensemble of initial states, "
+                    "fixed-work mode (max_AL_iter=1, cost_thresh=0)")
+    x0 = x0_fn(B, first)
 
     def run(iters):
-        phases = pkg.problems.wb_trot_problem()
-        s = pkg.MultiPhaseDDP(phases, batch=B, device=local)
+        s = pkg.MultiPhaseDDP(phases_fn(), batch=B, device=local)
         s.set_initial_condition(x0)
-        opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=iters, cost_thresh=0.0)
-        return s, opt
+        return s, opt_fn(iters)
 
     if args.warmup > 0:
         s, opt = run(args.warmup); s.solve(opt); s.close()
@@ -94,25 +142,15 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     s.solve(opt)                       # synchronises its stream before returning
-    info = s.info_arrays()
-    res = torch.tensor(np.stack([info["actual_cost"], info["dyn_feas"], info["max_tconstr"], info["max_pconstr"],
-                                 info["n_iters"].astype(np.float64), info["n_ls_iters"].astype(np.float64),
-                                 info["n_reg_iters"].astype(np.float64), info["status"].astype(np.float64)], axis=1),
-                       device=f"cuda:{local}")
-    if dist is not None:               # C1: all-gather of the per-problem result struct (64 B/problem) over RCCL/xGMI
-        gathered = [torch.empty_like(res) for _ in range(world)]
-        dist.all_gather(gathered, res)
-        res_all = torch.cat(gathered)
-    else:
-        res_all = res
+    rows = launch.result_rows(s.info_arrays())
+    res_all = launch.gather_results(dist, rows, dev)      # C1: all-gather of the per-problem result struct (64 B/problem) over RCCL/xGMI
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-    res_all = res_all.cpu().numpy()
+    dt = launch.max_over_ranks(dist, dt, dev)
+    ranks_seen = int(round(launch.sum_over_ranks(dist, 1.0, dev)))
+    assert res_all.shape[0] == total, (res_all.shape, total)
     iters_done = float(res_all[:, 4].sum())
     if rank == 0:
         kt = s.kernel_times()
@@ -121,28 +159,33 @@ def main():
         roof = None
         if dom:
             ms, n = kt[dom]
-            per_launch_bytes = ALG_BYTES[dom] * knots * B        # every launch covers the whole batch
+            units = s.kernel_units().get(dom)             # knots (x candidate steps) the launches of this kernel family processed
+            per_launch_bytes = ALG_BYTES[dom] * (units / n if units else knots * B)
             achieved = per_launch_bytes / (ms / n * 1e-3) / 1e9
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "avg_launch_ms": ms / n, "launches": n,
-                    "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()}}
-        line = {"metric": "DDP iterations/sec, Mini-Cheetah WB N=200, batch=4096; 1/2/4/8 GPU", "value": iters_done / dt, "unit": "DDP iterations/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "WB 36/12/12, N=200 = 4 contact phases x 50 knots (1111,0110,1001,0110), dt=0.01, ensemble of initial states, "
-                                       "fixed-work mode (max_AL_iter=1, cost_thresh=0)", "batch_per_gpu": B, "global_batch": B * world,
+                    "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
+                    "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()},
+                    "whole_iteration": {"alg_bytes_per_knot_iteration": 119280, "achieved_GBs": 119280.0 * knots * iters_done / dt / 1e9 / world,
+                                        "frac_of_peak": 119280.0 * knots * iters_done / dt / 1e9 / world / HBM_PEAK_GBS}}
+        line = {"metric": METRIC, "value": iters_done / dt, "unit": "DDP iterations/s",
+                "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": workload, "batch_per_gpu": B, "global_batch": total,
                            "parallelism": f"ensemble-sharded x{world}", "n_status_ok": int((res_all[:, 7] == 0).sum()),
                            "mean_ls_trials_per_iter": float(res_all[:, 5].sum() / max(iters_done, 1))},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, pkg.problems.wb_trot_problem, seed)
+            line["cpu_baseline"] = cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, args.steps)
+        if world == 1 and not args.no_latency and not args.strong:
+            line["latency"] = latency_probe(pkg, args.steps)
         print(json.dumps(line), flush=True)
     s.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

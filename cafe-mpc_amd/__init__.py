@@ -11,6 +11,7 @@ import os as _os
 from . import _abi
 from ._abi import Option, mhpc_ddp_setting, Solver, MODEL_WB, MODEL_SRB, MODEL_HKD  # noqa: F401
 from . import problems  # noqa: F401
+from . import launch  # noqa: F401
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 HIP_LIB_PATH = _os.path.join(_HERE, "libhsddp_hip.so")
@@ -60,3 +61,8 @@ class MultiPhaseDDP(Solver):
     def get_solver_info(self):
         a = self.info_arrays()
         return a["n_iters"], a["n_ls_iters"], a["n_reg_iters"], self.solve_time_ms()
+
+    def get_solver_info_buffers(self, problem=0):
+        """The second get_solver_info overload (MultiPhaseDDP.h:85): cost / dyn_feas / eqn_feas / ineq_feas history of one problem."""
+        hst = self.get_history(problem)
+        return hst["cost"], hst["dyn_feas"], hst["eqn_feas"], hst["ineq_feas"]

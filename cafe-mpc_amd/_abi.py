@@ -85,7 +85,8 @@ EXPORTS = ["hsddp_create", "hsddp_destroy", "hsddp_set_initial_condition", "hsdd
            "hsddp_hybrid_rollout", "hsddp_compute_cost", "hsddp_LQ_approximation", "hsddp_backward_sweep",
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
-           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_backend_name"]
+           "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_get_kernel_units", "hsddp_reset_kernel_times", "hsddp_get_history",
+           "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_backend_name"]
 
 
 def bind(lib):
@@ -112,6 +113,10 @@ def bind(lib):
     lib.hsddp_get_solve_time_ms.argtypes = [H]
     lib.hsddp_get_solve_time_ms.restype = C.c_float
     lib.hsddp_get_kernel_times.argtypes = [H, C.c_int, DP, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
+    lib.hsddp_get_kernel_units.argtypes = [H, C.c_char_p, C.POINTER(C.c_longlong)]
+    lib.hsddp_reset_kernel_times.argtypes = [H]
+    FP = C.POINTER(C.c_float)
+    lib.hsddp_get_history.argtypes = [H, C.c_int, C.c_int, FP, FP, FP, FP, IP]
     lib.hsddp_export_mpc_command.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     lib.hsddp_warm_start_phase.argtypes = [H, C.c_int, H, C.c_int, C.c_int]
     lib.hsddp_backend_name.argtypes = []
@@ -255,6 +260,23 @@ class Solver:
         for name, w, kind in self.CMD_FIELDS:
             seg = words[pos:pos + n_steps * w]; pos += n_steps * w
             out[name] = seg.view(np.float32 if kind == "f" else np.int32).reshape(n_steps, w).copy()
+        return out
+
+    def get_history(self, problem=0, cap=4096):
+        """MultiPhaseDDP::get_solver_info(cost, dyn_feas, eqn_feas, ineq_feas) (MultiPhaseDDP.h:85): the four float history buffers."""
+        bufs = [np.zeros(cap, dtype=np.float32) for _ in range(4)]
+        n = C.c_int()
+        FP = C.POINTER(C.c_float)
+        self._ck(self.lib.hsddp_get_history(self.h, problem, cap, *[b.ctypes.data_as(FP) for b in bufs], C.byref(n)), "get_history")
+        m = min(n.value, cap)
+        return {k: b[:m].copy() for k, b in zip(("cost", "dyn_feas", "eqn_feas", "ineq_feas"), bufs)}
+
+    def kernel_units(self):
+        out = {}
+        for k in ("k_rollout", "k_lq", "k_sweep"):
+            v = C.c_longlong()
+            if self.lib.hsddp_get_kernel_units(self.h, k.encode(), C.byref(v)) == 0:
+                out[k] = int(v.value)
         return out
 
     def kernel_times(self, max_n=32):

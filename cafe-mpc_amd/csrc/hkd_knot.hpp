@@ -76,10 +76,11 @@ HD double hkd_footreg(PhaseC& P, const double* x, int k) {
 }
 
 template <int NT>
-HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
+HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+    // ss: single shooting (MS = false, MultiPhaseDDP.cpp:65-68): X[k] is the state the previous knot of this wave simulated (Xsim[k]), no defect
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 24, ku = ((size_t)b * h + k) * 24, kk = (size_t)b * h + k;
-    HS_PHASE(NT, if (tid < 24) { double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; }
+    HS_PHASE(NT, if (tid < 24) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; }
              for (int i = tid; i < 576; i += NT) L.K[i] = P.K[kk * 576 + i];)
     HS_PHASE(NT, if (tid < 24) {
         double s = 0; for (int j = 0; j < 24; j++) s += L.K[tid + 24 * j] * (L.x[j] - L.xb[j]);
@@ -93,7 +94,7 @@ HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb
     HS_PHASE(NT, if (tid < 24) {
         const double xs = L.xn[tid];
         P.Xsim[kx + 24 + tid] = xs;
-        const double d = xs - (P.Xbar[kx + 24 + tid] + eps * P.dX[kx + 24 + tid]);
+        const double d = ss ? 0.0 : xs - (P.Xbar[kx + 24 + tid] + eps * P.dX[kx + 24 + tid]);
         P.Defect[kx + 24 + tid] = d;
         double dsq = d * d;
         if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 24 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 24 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
@@ -125,10 +126,10 @@ HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb
 // Terminal knot of an HKD phase: terminal cost, touchdown constraint (foot height of the legs about to land), reset map
 // (HKDReset.h:41-76: lift-off -> default joint angles, touchdown -> foot projected on the ground) into the next phase.
 template <int NT>
-HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot) {
+HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot, bool ss = false) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 24;
-    HS_PHASE(NT, if (tid < 24) { const double x = P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
+    HS_PHASE(NT, if (tid < 24) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
     HS_PHASE(NT, if (tid < 4 && P.td[tid]) {
         const V3<double> f = hkd_foot<double>(L.x + 3, L.x, L.x + 12 + 3 * tid, tid, md.cpsi_kin, md.spsi_kin);
         L.pf[3 * tid] = f.x; L.pf[3 * tid + 1] = f.y; L.pf[3 * tid + 2] = f.z;
@@ -158,7 +159,7 @@ HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& m
             if (!P.contact[l] && P.next_contact[l]) xi = (a < 2) ? L.pf[3 * l + a] : 0.0;
         }
         Pn->Xsim[nx + tid] = xi;
-        const double d = xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);
+        const double d = (ss || !Pn->shooting) ? 0.0 : xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);     // no shooting node at the start of the next phase: X[0] = x_init
         Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < 24; i++) s += L.red[i]; so.dsq[slot] = s; })

@@ -66,6 +66,12 @@ template <int NT> __device__ __forceinline__ void hs_phase_sync_all() { hs_phase
 // compiler-only memory barrier: stops the scheduler from hoisting a whole unrolled recurrence's LDS loads ahead of it
 // (hundreds of live registers); emits no instruction
 #define HS_CBAR() asm volatile("" ::: "memory")
+// same, and the value x must have been computed by this point (pins a dependent chain between two batches of loads)
+#ifdef HS_HOST_EMU
+#define HS_PIN(x)
+#else
+#define HS_PIN(x) asm volatile("" : "+v"(x) :: "memory")
+#endif
 
 namespace hs {
 

@@ -90,6 +90,7 @@ struct ProbState {
     int iter, ls_total, reg_total, status;
     int outer_active, inner_active, ls_active, ls_success, rollout_ok, bs_ok;
     int iter_in, iter_ou;
+    int hist_n, push_pending;            // entries in the history buffers; an entry waits for the next control step (see k_eval)
 };
 
 struct OptDev {

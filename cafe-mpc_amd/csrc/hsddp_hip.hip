@@ -3,7 +3,7 @@
 // Host driver of the batched HS-DDP solve: MultiPhaseDDP<T>::solve (HSDDPSolver/source/MultiPhaseDDP.cpp:216-447)
 // restructured as a per-problem state machine evaluated with masks over the whole batch, so that thousands of
 // independent problems advance through rollout / LQ approximation / Riccati sweep / line search in lock-step
-// kernel launches with no host round-trip inside an iteration (one 8-byte readback per inner iteration).
+// kernel launches; the host reads back one 16-byte activity counter per line-search launch and per inner iteration to stop early.
 // Kernels: wb_knot.hpp (one wavefront per knot), sweep.hpp (one workgroup per problem).
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -50,45 +50,73 @@ __device__ inline bool masked_out(const ProbState& s, int mask) {
     return false;
 }
 
+// Single shooting from phase `first` on, by ONE wave: every knot takes the state its predecessor simulated (SinglePhase.cpp:187,211-220).
+// Used for the young phases the receding-horizon update creates (SS_set empty, MHPCProblem.cpp:340-351; first > 0, stops at the next
+// phase with shooting nodes) and for the whole horizon when option.MS is false (MultiPhaseDDP.cpp:65-68; first = 0, descriptors with
+// every shooting flag cleared).  On entry the state to start from is in L.xnext (whole-body phase) / in Xsim[0] of the phase (SRB, HKD).
+__device__ void rollout_chain(WbCore& L, PhaseC* ph, int nph, int first, const ModelDev& md, int b, int nslots, double eps, const OptDev& opt, SlotOut so, int* fail) {
+    for (int pj = first; pj < nph && !ph[pj].shooting; pj++) {
+        PhaseC& Q = ph[pj]; PhaseC* Qn = pj + 1 < nph ? &ph[pj + 1] : nullptr; const size_t s0 = (size_t)b * nslots + Q.slot0;
+        if (Q.model == HSDDP_MODEL_WB) {
+            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
+            wb_rollout_terminal<64>(L, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
+        } else if (Q.model == HSDDP_MODEL_SRB) {
+            SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
+            for (int kq = 0; kq < Q.h; kq++) srb_rollout_knot<64>(Ls, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
+            srb_rollout_terminal<64>(Ls, Q, Qn, b, eps, so, s0 + Q.h, true);
+        } else {
+            HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
+            for (int kq = 0; kq < Q.h; kq++) hkd_rollout_knot<64>(Lh, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
+            hkd_rollout_terminal<64>(Lh, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
-                                               double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail) {
+                                               double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
+    if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);     // knots this launch rolls out (measurement only)
     __shared__ WbCore L;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
     const size_t slot = (size_t)b * nslots + s;
+    if (!ph[0].shooting) {       // single shooting over the whole horizon (option.MS = false): the wave of slot 0 walks every phase
+        if (s != 0) return;
+        const int n0 = ph[0].n;
+        if (ph[0].model == HSDDP_MODEL_WB) { HS_PHASE(64, if (tid < 36) L.xnext[tid] = x0[(size_t)b * 36 + tid];) }
+        else { HS_PHASE(64, if (tid < n0) ph[0].Xsim[(size_t)b * (ph[0].h + 1) * n0 + tid] = x0[(size_t)b * n0 + tid];) }
+        rollout_chain(L, ph, nph, 0, md, b, nslots, eps, opt, so, fail);
+        return;
+    }
+    if (!P.shooting) return;     // a phase without shooting nodes is rolled sequentially by the wave of its predecessor's terminal knot
     if (P.model == HSDDP_MODEL_HKD) {
         HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
         if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-        else hkd_rollout_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
+        else { hkd_rollout_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot); rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail); }
         return;
     }
     if (P.model == HSDDP_MODEL_SRB) {   // reduced-model tail of the MHPC horizon: a few hundred flops per knot, reuses the whole-body LDS block
         SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
         if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-        else srb_rollout_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b, eps, so, slot);
+        else { srb_rollout_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b, eps, so, slot); rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail); }
         return;
     }
-    if (!P.shooting) return;     // a phase without shooting nodes is rolled sequentially by the wave of its predecessor's terminal knot
     if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
     else {
         wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
-        for (int pj = pi + 1; pj < nph && !ph[pj].shooting; pj++) {      // single-shooting chain (young phases of the receding-horizon update)
-            PhaseC& Q = ph[pj]; const size_t s0 = (size_t)b * nslots + Q.slot0;
-            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
-            wb_rollout_terminal<64>(L, Q, pj + 1 < nph ? &ph[pj + 1] : nullptr, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
-        }
+        rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail);      // young single-shooting phases behind this one (if any)
     }
 }
 
 __global__ void __launch_bounds__(LQ_NT) LQ_ATTR k_lq(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
-                                          const ProbState* st, int mask, int use_cache) {
+                                          const ProbState* st, int mask, int use_cache, unsigned long long* units) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
+    if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);
     __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
@@ -136,10 +164,11 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slo
 }
 
 __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
-                                                int do_linear, double lin_eps, int* success_out) {
+                                                int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
     const PhaseDev* ph = ph_;   // (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there)
     const int b = blockIdx.x;
     if (masked_out(st[b], mask)) return;
+    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
     __shared__ SweepLds S;
     bool success = false;
     if (regularized) {   // MultiPhaseDDP::backward_sweep_regularized (MultiPhaseDDP.cpp:136-165)
@@ -264,8 +293,19 @@ __global__ void k_update_params(const PhaseDev* ph, int nph, OptDev opt, const P
 
 // Per-problem control: reduction of the per-slot partials + the scalar logic of MultiPhaseDDP::solve / line_search.
 enum { EV_REDUCE_ONLY = 0, EV_INIT, EV_OUTER_BEGIN, EV_INNER_BEGIN, EV_PRE_LS, EV_LS_TRIAL, EV_POST_LS, EV_OUTER_END, EV_TIMEOUT };
+// history buffers of MultiPhaseDDP (cost / dyn_feas / eqn_feas / ineq_feas_buffer, std::vector<float>, MultiPhaseDDP.h:133-136): [batch][4][cap]
+struct HistDev { float* buf; int cap; };
+__device__ inline void hist_push(const HistDev& hd, int b, ProbState& s) {      // MultiPhaseDDP.cpp:258-261, 382-385
+    const float tc = (float)s.max_tconstr, pc = (float)s.max_pconstr;
+    if (hd.buf != nullptr && s.hist_n < hd.cap) {
+        float* p = hd.buf + (size_t)b * 4 * hd.cap + s.hist_n;
+        p[0] = (float)s.actual_cost; p[hd.cap] = (float)s.feas; p[2 * hd.cap] = tc; p[3 * hd.cap] = pc;
+    }
+    s.hist_n++;
+    s.info_tconstr = tc; s.info_pconstr = pc;      // get_terminal / get_path_constraint_violation() = buffer.back() (MultiPhaseDDP.h:81-83)
+}
 __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa, ProbState* st, OptDev opt, double eps, const int* fail, int* do_update,
-                                            int* counters, int iter_ou_host) {
+                                            int* counters, int iter_ou_host, HistDev hd) {
     const int b = blockIdx.x, tid = threadIdx.x;
     ProbState& s = st[b];
     __shared__ double rc[64], rd[64], rg[64], rh[64];
@@ -280,12 +320,16 @@ __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa
         cost = rc[0]; dsq = rd[0]; ming = rg[0]; maxh = rh[0];
     }
     if (tid != 0) return;
+    // end of an inner iteration that ran to its last line (MultiPhaseDDP.cpp:382-385): the entry is buffered by the NEXT control step, so
+    // that a max_cputime stop at the reference's last checkpoint (:376-380, before the push) can still drop it
+    if (s.push_pending) { if (mode != EV_TIMEOUT) hist_push(hd, b, s); s.push_pending = 0; }
     switch (mode) {
     case EV_REDUCE_ONLY: s.actual_cost = cost; s.feas = sqrt(dsq); s.max_pconstr = ming; s.max_tconstr = maxh; break;
     case EV_INIT:   // MultiPhaseDDP.cpp:218-263
         s.actual_cost = cost; s.feas = sqrt(dsq); s.max_pconstr = ming; s.max_tconstr = maxh;
-        s.info_tconstr = maxh; s.info_pconstr = ming; s.iter = 0; s.ls_total = 0; s.status = 0; s.reg = 0;
+        s.iter = 0; s.ls_total = 0; s.status = 0; s.reg = 0;
         s.outer_active = 1; s.inner_active = 0; s.ls_active = 0; s.ls_success = 0; s.iter_in = 0; s.iter_ou = 0;
+        s.hist_n = 0; s.push_pending = 0; hist_push(hd, b, s);
         break;
     case EV_OUTER_BEGIN:   // :267-276
         if (s.outer_active) { s.iter_ou++; s.max_tconstr_prev = s.max_tconstr; s.max_pconstr_prev = s.max_pconstr; s.reg = 0; s.iter_in = 0; s.inner_active = 1; }
@@ -322,7 +366,7 @@ __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa
             s.ls_active = 0;
             if (!s.ls_success) { s.actual_cost = s.cost_prev; s.merit = s.merit_prev; }
             if ((fabs((s.cost_prev - s.actual_cost) / s.cost_prev) < opt.cost_thresh) && (s.feas <= opt.dynamics_feas_thresh)) s.inner_active = 0;
-            else { s.info_tconstr = s.max_tconstr; s.info_pconstr = s.max_pconstr; if (s.iter_in >= opt.max_DDP_iter) s.inner_active = 0; }
+            else { s.push_pending = 1; if (s.iter_in >= opt.max_DDP_iter) s.inner_active = 0; }
         }
         break;
     case EV_OUTER_END:     // :394-426
@@ -349,8 +393,12 @@ struct hsddp_handle {
     int nph = 0, batch = 0, device = 0, nslots = 0;
     std::vector<PhaseDev> ph;         // host copy (device pointers inside)
     PhaseDev* d_ph = nullptr;
+    PhaseDev* d_ph_ss = nullptr;      // the same descriptors with every shooting flag cleared: what option.MS = false rolls out (MultiPhaseDDP.cpp:65-68)
     int *d_slot_phase = nullptr, *d_slot_k = nullptr, *d_fail = nullptr, *d_do_update = nullptr, *d_counters = nullptr, *d_success = nullptr;
     int* h_counters = nullptr;        // pinned
+    unsigned long long* d_units = nullptr;   // knots processed by k_rollout / k_lq / k_sweep launches since the last reset (measurement)
+    float* d_hist = nullptr; int hist_cap = 0;      // history buffers [batch][4][hist_cap]
+    unsigned int* d_cmd = nullptr; size_t cmd_words = 0; int* d_cmd_map = nullptr; int cmd_steps = 0; float* d_cmd_status = nullptr;   // export staging (kept across calls)
     ProbState* d_st = nullptr;
     double* d_x0 = nullptr;
     SlotArrays sa{};
@@ -386,19 +434,20 @@ template <class T> static int dalloc(hsddp_handle* h, T** out, size_t count, boo
     void* p = nullptr; size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed: %s\n", bytes, hipGetErrorString(e)); return HSDDP_ENOMEM; }
-    if (zero) hipMemset(p, 0, bytes);
-    h->allocs.push_back(p); *out = (T*)p; return HSDDP_OK;
-}
-template <class T> static int dupload(hsddp_handle* h, const T** out, const T* src, size_t count) {
-    T* p = nullptr; int rc = dalloc(h, &p, count, src == nullptr); if (rc) return rc;
-    if (src) hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
-    *out = p; return HSDDP_OK;
+    h->allocs.push_back(p);
+    if (zero && (e = hipMemset(p, 0, bytes)) != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMemset(%zu) failed: %s\n", bytes, hipGetErrorString(e)); return HSDDP_ENODEV; }
+    *out = (T*)p; return HSDDP_OK;
 }
 
 // record 0 -> records 1..count-1 by doubling device-to-device copies (log2(count) calls instead of `count`)
-static void dev_replicate(void* base, size_t one, size_t count) {
+static hipError_t dev_replicate(void* base, size_t one, size_t count) {
     size_t have = 1;
-    while (have < count) { size_t n = std::min(have, count - have); hipMemcpy((char*)base + have * one, base, n * one, hipMemcpyDeviceToDevice); have += n; }
+    while (have < count) {
+        size_t n = std::min(have, count - have);
+        hipError_t e = hipMemcpy((char*)base + have * one, base, n * one, hipMemcpyDeviceToDevice); if (e != hipSuccess) return e;
+        have += n;
+    }
+    return hipSuccess;
 }
 
 static OptDev to_dev(const hsddp_option_t& o) {
@@ -418,54 +467,74 @@ void hsddp_destroy(hsddp_handle_t* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
     for (void* p : h->allocs) hipFree(p);
+    if (h->d_hist) hipFree(h->d_hist);
+    if (h->d_cmd) hipFree(h->d_cmd);
+    if (h->d_cmd_map) hipFree(h->d_cmd_map);
+    if (h->d_cmd_status) hipFree(h->d_cmd_status);
     for (auto e : h->pool) hipEventDestroy(e);
     if (h->h_counters) hipHostFree(h->h_counters);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
 
+// HIP memory policy of setup_phase (hs_host.hpp): every call checked, the first failure is remembered
+struct HipMem {
+    hsddp_handle* h; hipError_t err = hipSuccess;
+    void fail(hipError_t e, const char* what, size_t bytes) { if (err == hipSuccess) { err = e; fprintf(stderr, "[hsddp_hip] %s(%zu) failed: %s\n", what, bytes, hipGetErrorString(e)); } }
+    void* alloc(size_t bytes) {
+        void* p = nullptr; bytes = std::max<size_t>(bytes, 8);
+        hipError_t e = hipMalloc(&p, bytes); if (e != hipSuccess) { fail(e, "hipMalloc", bytes); return nullptr; }
+        h->allocs.push_back(p);
+        e = hipMemset(p, 0, bytes); if (e != hipSuccess) fail(e, "hipMemset", bytes);
+        return p;
+    }
+    void upload(void* dst, const void* src, size_t bytes) { hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); if (e != hipSuccess) fail(e, "hipMemcpy H2D", bytes); }
+    void replicate(void* base, size_t one, size_t count) { hipError_t e = dev_replicate(base, one, count); if (e != hipSuccess) fail(e, "hipMemcpy D2D", one * count); }
+};
+
 int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
     if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
     for (int i = 0; i < n_phases; i++) {
         if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB && phases[i].model != HSDDP_MODEL_HKD) return HSDDP_EINVAL;
         if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) { fprintf(stderr, "[hsddp_hip] phase %d: the reference has no reset map from model %d to model %d (MHPCReset.cpp:4-52, HKDReset.h)\n", i, phases[i - 1].model, phases[i].model); return HSDDP_ENOTSUP; }
-        if (!phases[i].shooting && (i == 0 || phases[i].model != HSDDP_MODEL_WB)) { fprintf(stderr, "[hsddp_hip] phase %d: a phase without shooting nodes must be a whole-body phase behind another phase (the young phases of MHPCProblem::update)\n", i); return HSDDP_ENOTSUP; }
+        if (!phases[i].shooting && i == 0) { fprintf(stderr, "[hsddp_hip] phase 0 must have shooting nodes (single shooting over the whole horizon is option.MS = 0)\n"); return HSDDP_ENOTSUP; }
         if (phases[i].horizon <= 0) return HSDDP_EINVAL;
     }
-    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { fprintf(stderr, "[hsddp_hip] no HIP device %d\n", device); return HSDDP_ENODEV; }
+    int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { fprintf(stderr, "[hsddp_hip] no HIP device %d\n", device); return HSDDP_ENODEV; }
     HIPCK(hipSetDevice(device));
     hsddp_handle* h = new hsddp_handle();
     h->nph = n_phases; h->batch = batch; h->device = device;
-    HIPCK(hipStreamCreate(&h->stream));
+    // from here on every failure goes through hsddp_destroy(h): nothing allocated so far is leaked
+#define CREATE_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); hsddp_destroy(h); return HSDDP_ENODEV; } } while (0)
+    CREATE_CK(hipStreamCreate(&h->stream));
     double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI;
     h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
     h->ph.resize(n_phases);
     std::vector<int> sp, sk;
     const size_t B = batch;
     int rc = 0;
-    struct HipMem {
-        hsddp_handle* h;
-        void* alloc(size_t bytes) { void* p = nullptr; bytes = std::max<size_t>(bytes, 8); if (hipMalloc(&p, bytes) != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed\n", bytes); return nullptr; } hipMemset(p, 0, bytes); h->allocs.push_back(p); return p; }
-        void upload(void* dst, const void* src, size_t bytes) { hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
-        void replicate(void* base, size_t one, size_t count) { dev_replicate(base, one, count); }
-    } mem{h};
+    HipMem mem{h};
     for (int i = 0; i < n_phases && !rc; i++) {
         rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, h->ph[i], (int)sp.size());
+        if (!rc && mem.err != hipSuccess) rc = (mem.err == hipErrorOutOfMemory) ? HSDDP_ENOMEM : HSDDP_ENODEV;
         for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
     }
     h->nslots = (int)sp.size();
-    if (!rc) rc |= dalloc(h, &h->d_ph, n_phases);
+    if (!rc) rc |= dalloc(h, &h->d_ph, n_phases); if (!rc) rc |= dalloc(h, &h->d_ph_ss, n_phases);
     if (!rc) rc |= dalloc(h, &h->d_slot_phase, sp.size()); if (!rc) rc |= dalloc(h, &h->d_slot_k, sk.size());
     if (!rc) rc |= dalloc(h, &h->d_fail, B); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
-    if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n);
+    if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n); if (!rc) rc |= dalloc(h, &h->d_units, 8);
     if (!rc) rc |= dalloc(h, &h->sa.cost, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * sp.size());
     if (!rc) rc |= dalloc(h, &h->sa.ming, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * sp.size());
     if (rc) { hsddp_destroy(h); return rc; }
-    hipMemcpy(h->d_ph, h->ph.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice);
-    hipMemcpy(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice);
-    hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int));
-    HIPCK(hipDeviceSynchronize());
+    std::vector<PhaseDev> ss = h->ph; for (auto& q : ss) q.shooting = 0;
+    CREATE_CK(hipMemcpy(h->d_ph, h->ph.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
+    CREATE_CK(hipMemcpy(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
+    CREATE_CK(hipMemcpy(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
+    CREATE_CK(hipMemcpy(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice));
+    CREATE_CK(hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int)));
+    CREATE_CK(hipDeviceSynchronize());
+#undef CREATE_CK
     *out = h; return HSDDP_OK;
 }
 
@@ -483,12 +552,12 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     h->cache_valid = false;
     if (Xbar) {
         HIPCK(hipMemcpy(P.Xbar, Xbar, (per_problem ? B : 1) * sx * 8, hipMemcpyHostToDevice));
-        if (!per_problem) dev_replicate(P.Xbar, sx * 8, B);
+        if (!per_problem) HIPCK(dev_replicate(P.Xbar, sx * 8, B));
         HIPCK(hipMemcpy(P.X, P.Xbar, B * sx * 8, hipMemcpyDeviceToDevice));
     }
     if (Ubar) {
         HIPCK(hipMemcpy(P.Ubar, Ubar, (per_problem ? B : 1) * su * 8, hipMemcpyHostToDevice));
-        if (!per_problem) dev_replicate(P.Ubar, su * 8, B);
+        if (!per_problem) HIPCK(dev_replicate(P.Ubar, su * 8, B));
         HIPCK(hipMemcpy(P.U, P.Ubar, B * su * 8, hipMemcpyDeviceToDevice));
     }
     HIPCK(hipMemset(P.K, 0, B * P.h * P.m * P.n * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
@@ -496,17 +565,19 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
 }
 
 // ---- launch helpers
+enum { UNIT_ROLLOUT = 0, UNIT_LQ = 1, UNIT_SWEEP = 2 };
+static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}; }
 static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask) {
     Timed t(h, "k_rollout");
     hipMemsetAsync(h->d_fail, 0, h->batch * sizeof(int), h->stream);
-    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md,
-                       eps, o, h->d_x0, h->sa, h->d_st, mask, h->d_fail);
+    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md,
+                       eps, o, h->d_x0, h->sa, h->d_st, mask, h->d_fail, h->d_units + UNIT_ROLLOUT);
     if (mask == MASK_NONE) h->cache_valid = true;     // masked launches only refresh problems whose cache was valid already
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_lq");
     hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(LQ_NT), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
-                       h->cache_valid ? 1 : 0);
+                       h->cache_valid ? 1 : 0, h->d_units + UNIT_LQ);
 }
 static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_cost");
@@ -514,12 +585,12 @@ static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
 }
 static void launch_sweep(hsddp_handle* h, const OptDev& o, int mask, double reg, int regularized, int do_linear, double lin_eps, int* succ) {
     Timed t(h, "k_sweep");
-    hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ);
+    hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
 }
 static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, bool count, int iter_ou) {
     Timed t(h, "k_eval");
     if (count) hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
-    hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou);
+    hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou, hist_of(h));
     if (count) hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
 }
 static void launch_update_nominal(hsddp_handle* h, int mask) {
@@ -529,9 +600,16 @@ static void launch_update_nominal(hsddp_handle* h, int mask) {
 
 int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_ms) {
     if (!h || !opt) return HSDDP_EINVAL;
-    if (!opt->MS) { fprintf(stderr, "[hsddp_hip] MS=false (single shooting) is not supported on the HIP backend\n"); return HSDDP_ENOTSUP; }
     HIPCK(hipSetDevice(h->device));
     const OptDev o = to_dev(*opt);
+    {   // history buffers: one entry after the initial rollout + one per completed inner iteration (MultiPhaseDDP.cpp:258-261, 382-385)
+        const long long want = 1 + (long long)std::max(opt->max_AL_iter, 0) * std::max(opt->max_DDP_iter, 0);
+        const int cap = (int)std::min<long long>(want, 4096);
+        if (cap > h->hist_cap) {
+            if (h->d_hist) { HIPCK(hipStreamSynchronize(h->stream)); HIPCK(hipFree(h->d_hist)); h->d_hist = nullptr; h->hist_cap = 0; }
+            HIPCK(hipMalloc((void**)&h->d_hist, (size_t)h->batch * 4 * cap * sizeof(float))); h->hist_cap = cap;
+        }
+    }
     auto t0 = std::chrono::high_resolution_clock::now();
     auto elapsed = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(); };
     const bool budget = max_cputime_ms < 1e5f;
@@ -549,7 +627,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             if (timeup()) { timed_out = true; break; }
             launch_lq(h, o, MASK_INNER);
             if (timeup()) { timed_out = true; break; }
-            launch_sweep(h, o, MASK_INNER, 0.0, 1, 1, 1.0, nullptr);
+            launch_sweep(h, o, MASK_INNER, 0.0, 1, o.MS ? 1 : 0, 1.0, nullptr);      // (linear rollout only with multiple shooting, MultiPhaseDDP.cpp:326-329)
             if (timeup()) { timed_out = true; break; }
             launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
             double eps = 1.0;
@@ -586,7 +664,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
 
 // ---- step API (MultiPhaseDDP public methods)
 int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
-    if (!h || !opt) return HSDDP_EINVAL; if (!opt->MS) return HSDDP_ENOTSUP;
+    if (!h || !opt) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device)); OptDev o = to_dev(*opt);
     launch_rollout(h, eps, o, MASK_NONE); launch_eval(h, EV_REDUCE_ONLY, o, 0.0, false, 0);
     HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
@@ -621,10 +699,12 @@ static int read_states(hsddp_handle* h, std::vector<ProbState>& st) {
     HIPCK(hipMemcpy(st.data(), h->d_st, sizeof(ProbState) * h->batch, hipMemcpyDeviceToHost)); return HSDDP_OK;
 }
 int hsddp_get_exp_cost_change(hsddp_handle_t* h, double* dV_1, double* dV_2) {
+    if (!h || !dV_1 || !dV_2) return HSDDP_EINVAL;
     std::vector<ProbState> st; int rc = read_states(h, st); if (rc) return rc;
     for (int b = 0; b < h->batch; b++) { dV_1[b] = st[b].dV_1; dV_2[b] = st[b].dV_2; } return HSDDP_OK;
 }
 int hsddp_measure_dynamics_feasibility(hsddp_handle_t* h, double* feas) {
+    if (!h || !feas) return HSDDP_EINVAL;
     std::vector<ProbState> st; int rc = read_states(h, st); if (rc) return rc;
     for (int b = 0; b < h->batch; b++) feas[b] = st[b].feas; return HSDDP_OK;
 }
@@ -635,6 +715,17 @@ int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) {
         info[b].actual_cost = st[b].actual_cost; info[b].dyn_feas = st[b].feas; info[b].max_tconstr = st[b].info_tconstr; info[b].max_pconstr = st[b].info_pconstr;
         info[b].n_iters = st[b].iter; info[b].n_ls_iters = st[b].ls_total; info[b].n_reg_iters = st[b].reg_total; info[b].status = st[b].status;
     }
+    return HSDDP_OK;
+}
+
+int hsddp_get_history(hsddp_handle_t* h, int problem, int cap, float* cost, float* dyn_feas, float* eqn_feas, float* ineq_feas, int* n) {
+    if (!h || problem < 0 || problem >= h->batch || cap < 0 || !n) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    ProbState st; HIPCK(hipMemcpy(&st, h->d_st + problem, sizeof(ProbState), hipMemcpyDeviceToHost));
+    const int have = std::min(st.hist_n, h->hist_cap); *n = have;
+    const int m = std::min(have, cap);
+    float* dst[4] = {cost, dyn_feas, eqn_feas, ineq_feas};
+    for (int q = 0; q < 4 && m > 0; q++) if (dst[q]) HIPCK(hipMemcpy(dst[q], h->d_hist + ((size_t)problem * 4 + q) * h->hist_cap, m * sizeof(float), hipMemcpyDeviceToHost));
     return HSDDP_OK;
 }
 
@@ -678,15 +769,29 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double
     if ((int)sp.size() < n_steps) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
     const size_t words = 1 + (size_t)n_steps * HSDDP_CMD_WORDS_PER_STEP;
-    unsigned int* d_out = nullptr; int* d_map = nullptr; float* d_status = nullptr;
-    HIPCK(hipMalloc(&d_out, words * 4)); HIPCK(hipMalloc(&d_map, 2 * n_steps * sizeof(int)));
-    HIPCK(hipMemcpy(d_map, sp.data(), n_steps * sizeof(int), hipMemcpyHostToDevice)); HIPCK(hipMemcpy(d_map + n_steps, sk.data(), n_steps * sizeof(int), hipMemcpyHostToDevice));
-    if (status_times) { HIPCK(hipMalloc(&d_status, h->nph * 4 * sizeof(float))); HIPCK(hipMemcpy(d_status, status_times, h->nph * 4 * sizeof(float), hipMemcpyHostToDevice)); }
-    hipLaunchKernelGGL(k_pack_command, dim3(n_steps), dim3(256), 0, h->stream, h->d_ph, d_map, d_map + n_steps, n_steps, problem, mpc_time, dt, d_status, d_out);
+    // staging buffers live in the handle (an MPC tick must not pay hipMalloc / hipFree): grown on demand, freed by hsddp_destroy
+    if (words > h->cmd_words) { if (h->d_cmd) HIPCK(hipFree(h->d_cmd)); h->d_cmd = nullptr; h->cmd_words = 0; HIPCK(hipMalloc((void**)&h->d_cmd, words * 4)); h->cmd_words = words; }
+    if (n_steps > h->cmd_steps) { if (h->d_cmd_map) HIPCK(hipFree(h->d_cmd_map)); h->d_cmd_map = nullptr; h->cmd_steps = 0; HIPCK(hipMalloc((void**)&h->d_cmd_map, 2 * (size_t)n_steps * sizeof(int))); h->cmd_steps = n_steps; }
+    if (status_times && !h->d_cmd_status) HIPCK(hipMalloc((void**)&h->d_cmd_status, (size_t)h->nph * 4 * sizeof(float)));
+    HIPCK(hipMemcpyAsync(h->d_cmd_map, sp.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCK(hipMemcpyAsync(h->d_cmd_map + n_steps, sk.data(), n_steps * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (status_times) HIPCK(hipMemcpyAsync(h->d_cmd_status, status_times, (size_t)h->nph * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack_command, dim3(n_steps), dim3(256), 0, h->stream, h->d_ph, h->d_cmd_map, h->d_cmd_map + n_steps, n_steps, problem, mpc_time, dt,
+                       status_times ? h->d_cmd_status : nullptr, h->d_cmd);
+    HIPCK(hipMemcpyAsync(out, h->d_cmd, words * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
-    HIPCK(hipMemcpy(out, d_out, words * 4, hipMemcpyDeviceToHost));
-    hipFree(d_out); hipFree(d_map); if (d_status) hipFree(d_status);
     return HSDDP_OK;
+}
+
+// knots processed by the launches of a kernel family since the last hsddp_reset_kernel_times (masked launches skip problems: the
+// roofline figure of bench.py divides algorithmic bytes by what a launch really processed)
+int hsddp_get_kernel_units(hsddp_handle_t* h, const char* name, long long* units) {
+    if (!h || !name || !units) return HSDDP_EINVAL;
+    const int id = !strcmp(name, "k_rollout") ? UNIT_ROLLOUT : !strcmp(name, "k_lq") ? UNIT_LQ : !strcmp(name, "k_sweep") ? UNIT_SWEEP : -1;
+    if (id < 0) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    unsigned long long v = 0; HIPCK(hipMemcpy(&v, h->d_units + id, sizeof(v), hipMemcpyDeviceToHost));
+    *units = (long long)v; return HSDDP_OK;
 }
 
 int hsddp_get_kernel_times(hsddp_handle_t* h, int max_n, double* ms, long long* launches, char* names, int names_cap) {
@@ -714,7 +819,12 @@ int hsddp_debug_sweep_prof(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
-int hsddp_reset_kernel_times(hsddp_handle_t* h) { if (!h) return HSDDP_EINVAL; for (auto& v : h->kms) v = 0; for (auto& v : h->kcnt) v = 0; return HSDDP_OK; }
+int hsddp_reset_kernel_times(hsddp_handle_t* h) {
+    if (!h) return HSDDP_EINVAL;
+    for (auto& v : h->kms) v = 0; for (auto& v : h->kcnt) v = 0;
+    HIPCK(hipSetDevice(h->device)); HIPCK(hipMemset(h->d_units, 0, 8 * sizeof(unsigned long long)));
+    return HSDDP_OK;
+}
 
 }  // extern "C"
 #endif

@@ -54,10 +54,11 @@ struct SrbLds {
 
 // Rollout of one SRB knot k < h of problem b (SinglePhase::forward_sweep body with the SRB callbacks).
 template <int NT>
-HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag) {
+HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+    // ss: single shooting (MS = false, MultiPhaseDDP.cpp:65-68): X[k] is the state the previous knot of this wave simulated (Xsim[k]), no defect
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 12, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
-    HS_PHASE(NT, if (tid < 12) { double xb = P.Xbar[kx + tid], x = xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; }
+    HS_PHASE(NT, if (tid < 12) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; }
              for (int i = tid; i < 144; i += NT) L.K[i] = P.K[kk * 144 + i];)
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 12; j++) s += L.K[tid + 12 * j] * (L.x[j] - L.xb[j]);
@@ -68,7 +69,7 @@ HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb
     HS_PHASE(NT, if (tid < 12) {
         const double xs = L.x[tid] + L.xd[tid] * P.dt;
         P.Xsim[kx + 12 + tid] = xs;
-        const double d = xs - (P.Xbar[kx + 12 + tid] + eps * P.dX[kx + 12 + tid]);
+        const double d = ss ? 0.0 : xs - (P.Xbar[kx + 12 + tid] + eps * P.dX[kx + 12 + tid]);
         P.Defect[kx + 12 + tid] = d;
         double dsq = d * d;
         if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 12 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 12 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
@@ -95,10 +96,10 @@ HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb
 
 // Terminal knot of an SRB phase: quadratic terminal cost; the reset map to a following SRB phase is the identity.
 template <int NT>
-HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps, SlotOut so, size_t slot) {
+HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps, SlotOut so, size_t slot, bool ss = false) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 12;
-    HS_PHASE(NT, if (tid < 12) { const double x = P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
+    HS_PHASE(NT, if (tid < 12) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
     HS_PHASE(NT, if (tid == 0) {
         double s = 0; for (int i = 0; i < 12; i++) { const double d = L.x[i] - P.xr[(size_t)h * 12 + i]; s += d * P.qf[i] * d; }
         const double Phi = 0.5 * s;
@@ -110,7 +111,7 @@ HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps
     HS_PHASE(NT, if (tid < 12) {
         const double xi = L.x[tid];
         Pn->Xsim[nx + tid] = xi;
-        const double d = xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);
+        const double d = (ss || !Pn->shooting) ? 0.0 : xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);     // no shooting node at the start of the next phase: X[0] = x_init
         Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < 12; i++) s += L.red[i]; so.dsq[slot] = s; })

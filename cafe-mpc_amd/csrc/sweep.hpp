@@ -34,6 +34,9 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 #endif
 #define HS_STR_(x) #x
 #define HS_UNROLL_N(n) _Pragma(HS_STR_(unroll n))
+#ifndef SW_LDLT_NB
+#define SW_LDLT_NB ((M <= 12) ? 2 : 1)
+#endif
 #ifndef SW_MINB
 #define SW_MINB 2
 #endif
@@ -184,36 +187,48 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
         // ---- row `me` of the permuted matrix (lower triangle of the input only)
         double arow[M];
         _Pragma("unroll") for (int j = 0; j < M; j++) { const int r = prow > pv[j] ? prow : pv[j], c = prow > pv[j] ? pv[j] : prow; arow[j] = A[r + LD * c] + ((j == me) ? diag_add : 0.0); }
-        // ---- left-looking LDL^T
-        double lrow[M], dk[M]; int sign = 0;
-        _Pragma("unroll") for (int k = 0; k < M; k++) {
-            double t = 0.0;
-            _Pragma("unroll") for (int j = 0; j < k; j++) t += lrow[j] * (dk[j] * hs_readlane(lrow[j], k));
-            const double vv = arow[k] - t;
-            const double d = hs_readlane(vv, k);
-            dk[k] = d;
-            lrow[k] = (fabs(d) > 0.0) ? vv / d : vv;
-            if (sign == 1) { if (d < 0) sign = 2; } else if (sign == -1) { if (d > 0) sign = 2; } else { if (d > 0) sign = 1; else if (d < 0) sign = -1; }
+        // ---- LDL^T of the permuted matrix, right-looking with the row in registers (the structure of chol_r): at step j every lane holds
+        //      its column-j entry w = D_j L(me,j) of the current Schur complement in a[j]; the pivot D_j = w of lane j and the entries of
+        //      the other rows travel by constant-lane broadcasts: a[k] -= L(me,j) * (D_j L(k,j)).  Same pivots and multipliers as Eigen's
+        //      left-looking loops (A(k,k) -= L temp, A21 = (A21 - A20 temp) / A(k,k)) up to the association of the partial sums; quotients
+        //      by the pivot as multiplications by its reciprocal.  Multipliers and reciprocal pivots go straight to LDS (row me of Lw).
+        bool anyneg = false;
+        _Pragma("unroll") for (int j = 0; j < M; j++) {
+            const double d = hs_readlane(arow[j], j);
+            double rd = __builtin_amdgcn_rcp(d); rd = rd * (2.0 - d * rd); rd = rd * (2.0 - d * rd);     // 1/d to the last bit or two (the IEEE division sequence is five times as long and sits on the chain from pivot to pivot)
+            rd = (fabs(d) > TOL) ? rd : 0.0;
+            anyneg = anyneg || (d < 0.0);
+            const double lij = (fabs(d) > 0.0) ? arow[j] * rd : arow[j];
+            if (act) { if (me > j) Lw[me * M + j] = lij; else if (me == j) Lw[j * M + j] = rd; }
+            _Pragma("unroll") for (int k = j + 1; k < M; k++) arow[k] -= lij * hs_readlane(arow[j], k);
         }
-        if (tid == 0 && !(sign == 1 || sign == 0)) *ok = 0;
-        if (act) { _Pragma("unroll") for (int j = 0; j < M - 1; j++) if (j < me) Lw[me * M + j] = lrow[j]; }
+        if (tid == 0 && anyneg) *ok = 0;       // isPositive(): no negative pivot (Eigen's sign bookkeeping ends in PositiveSemiDef / ZeroSign exactly then)
+        // ---- column `me` of the inverse: P e_me is the unit vector at position myrank.  The factor row of the next step is fetched
+        //      (broadcast reads) while the current row's multiply-add chain runs: a single wave has nothing else to hide the LDS latency behind.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- column `me` of the inverse: P e_me is the unit vector at position myrank
-        if (act) {
-            double y[M];
-            _Pragma("unroll") for (int k = 0; k < M; k++) {
-                double s = (k == myrank) ? 1.0 : 0.0;
-                _Pragma("unroll") for (int j = 0; j < k; j++) s -= Lw[k * M + j] * y[j];
-                y[k] = s; if (k % 4 == 3) HS_CBAR();
-            }
-            _Pragma("unroll") for (int k = 0; k < M; k++) y[k] = (fabs(dk[k]) > TOL) ? y[k] / dk[k] : 0.0;
-            _Pragma("unroll") for (int k = M - 1; k >= 0; k--) {
-                double s = y[k];
-                _Pragma("unroll") for (int j = k + 1; j < M; j++) s -= Lw[j * M + k] * y[j];
-                y[k] = s; if (k % 4 == 0) HS_CBAR();
-            }
-            _Pragma("unroll") for (int k = 0; k < M; k++) NI[pv[k] + LD * me] = -y[k];
+        constexpr int NB = SW_LDLT_NB;      // (the 24-row factor of the kinodynamic model leaves no registers for a second row buffer)
+        double y[M], lr[NB][M];
+        if (NB == 1) { lr[0][0] = 0.0; }
+        _Pragma("unroll") for (int k = 0; k < M; k++) {
+            if (NB == 2) { if (k + 1 < M) { _Pragma("unroll") for (int j = 0; j <= k; j++) lr[(k + 1) % NB][j] = Lw[(k + 1) * M + j]; } }
+            else { _Pragma("unroll") for (int j = 0; j < k; j++) lr[0][j] = Lw[k * M + j]; }
+            HS_CBAR();
+            double sacc = (k == myrank) ? 1.0 : 0.0;
+            _Pragma("unroll") for (int j = 0; j < k; j++) sacc -= lr[k % NB][j] * y[j];
+            HS_PIN(sacc);       // (the row's chain is evaluated HERE: otherwise every row's loads are issued first and their values spill)
+            y[k] = sacc;
         }
+        _Pragma("unroll") for (int k = 0; k < M; k++) y[k] = y[k] * Lw[k * M + k];
+        _Pragma("unroll") for (int k = M - 1; k >= 0; k--) {
+            if (NB == 2) { if (k > 0) { _Pragma("unroll") for (int j = k; j < M; j++) lr[(k - 1) % NB][j] = Lw[j * M + (k - 1)]; } }
+            else { _Pragma("unroll") for (int j = k + 1; j < M; j++) lr[0][j] = Lw[j * M + k]; }
+            HS_CBAR();
+            double sacc = y[k];
+            _Pragma("unroll") for (int j = k + 1; j < M; j++) sacc -= lr[k % NB][j] * y[j];
+            HS_PIN(sacc);
+            y[k] = sacc;
+        }
+        if (act) { _Pragma("unroll") for (int k = 0; k < M; k++) NI[pv[k] + LD * me] = -y[k]; }
     })
 #endif
 }

@@ -69,6 +69,13 @@ public:
     void get_solver_info(int& n_iters, int& n_ls_iters, int& n_reg_iters, float& solve_time, int b = 0) const {
         n_iters = info_.at(b).n_iters; n_ls_iters = info_.at(b).n_ls_iters; n_reg_iters = info_.at(b).n_reg_iters; solve_time = hsddp_get_solve_time_ms(h_);
     }
+    // the history overload (MultiPhaseDDP.h:85): cost / dynamics feasibility / terminal / path constraint violation after the initial
+    // rollout and after every completed inner iteration
+    void get_solver_info(std::vector<float>& cost, std::vector<float>& dyn_feas, std::vector<float>& eqn_feas, std::vector<float>& ineq_feas, int b = 0) {
+        int n = 0; rc_ = hsddp_get_history(h_, b, 0, nullptr, nullptr, nullptr, nullptr, &n);
+        cost.assign(n, 0.f); dyn_feas.assign(n, 0.f); eqn_feas.assign(n, 0.f); ineq_feas.assign(n, 0.f);
+        if (rc_ == HSDDP_OK && n > 0) rc_ = hsddp_get_history(h_, b, n, cost.data(), dyn_feas.data(), eqn_feas.data(), ineq_feas.data(), &n);
+    }
     int status(int b = 0) const { return info_.at(b).status; }
 
     // results live in the handle (the reference mutates caller-owned Trajectory objects in place); copy a field out

@@ -1,0 +1,111 @@
+"""One process per GPU: rank start-up, ensemble sharding and the single collective of the multi-GPU path.
+
+The HS-DDP path shards by independent problems: rank r owns a contiguous block of the ensemble, solves it with its own handle and no
+data-path collective; one all-gather of the 64-byte per-problem result struct (RCCL over xGMI; `nccl` IS RCCL on ROCm) puts every
+problem's outcome on every rank (arg-min over contact-schedule candidates, MHPCLocomotion-style consumers).  bench.py and the CPU
+rehearsal in tests/test_sharding_gloo.py (gloo) go through the same functions.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+RESULT_FIELDS = ("actual_cost", "dyn_feas", "max_tconstr", "max_pconstr", "n_iters", "n_ls_iters", "n_reg_iters", "status")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_spawn(n_ranks, script, argv, require_gpus=True):
+    """Parent side of `bench.py --gpus N` started WITHOUT a launcher: start N ranks (torch.distributed.run, one per GPU) as child
+    processes and relay their output.  Must run before this process makes any GPU call (a process that has initialised the GPU must
+    not exec or fork GPU work).  Returns None when this process is itself a rank (or N == 1), else the children's exit code."""
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != n_ranks:
+            print(f"[launch] --gpus {n_ranks} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks", file=sys.stderr)
+            raise SystemExit(2)
+        return None
+    if n_ranks <= 1:
+        return None
+    if require_gpus:
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU
+        if have < n_ranks:
+            print(f"[launch] --gpus {n_ranks} requested but this node exposes {have} GPU(s): refusing to run fewer ranks than asked", file=sys.stderr)
+            return 3
+    port = free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(backend):
+    """(rank, world, local_rank, dist or None).  backend: "nccl" (RCCL, one GPU per rank) or "gloo" (CPU rehearsal)."""
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return 0, 1, local, None
+    import torch
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend=backend)
+    seen = dist.get_world_size()
+    if seen != world:
+        raise RuntimeError(f"process group reports {seen} ranks, launcher announced {world}")
+    return rank, world, local, dist
+
+
+def shard(total, world, rank):
+    """Contiguous block [first, first + count) of `total` problems owned by `rank` (blocks differ by at most one problem)."""
+    base, rem = divmod(total, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def result_rows(info):
+    """hsddp_info_t arrays -> [problems, 8] fp64 rows (the 64-byte result struct of SURVEY 8e)."""
+    return np.stack([np.asarray(info[k], dtype=np.float64) for k in RESULT_FIELDS], axis=1)
+
+
+def gather_results(dist, rows, device):
+    """All-gather of the per-problem result rows (blocks may differ in length by one: padded to the longest, trimmed after)."""
+    import torch
+    if dist is None:
+        return rows
+    world = dist.get_world_size()
+    n = torch.tensor([rows.shape[0]], device=device, dtype=torch.int64)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    nmax = int(max(int(x.item()) for x in ns))
+    pad = torch.zeros((nmax, rows.shape[1]), device=device, dtype=torch.float64)
+    pad[:rows.shape[0]] = torch.as_tensor(rows, device=device)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return np.concatenate([o[:int(c.item())].cpu().numpy() for o, c in zip(out, ns)])
+
+
+def max_over_ranks(dist, value, device):
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(dist, value, device):
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

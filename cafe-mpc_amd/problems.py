@@ -57,6 +57,10 @@ class SplitMix64:
     def __init__(self, seed):
         self.s = seed & self.M
 
+    def skip(self, n):
+        """Advance the stream by n draws (splitmix64's state is a counter: any shard can jump to its own slice)."""
+        self.s = (self.s + n * 0x9E3779B97F4A7C15) & self.M
+
     def next(self):
         self.s = (self.s + 0x9E3779B97F4A7C15) & self.M
         z = self.s
@@ -77,7 +81,7 @@ def wb_ensemble_x0(batch, seed, first=0):
     xn = wb_nominal_state()
     out = np.zeros((batch, 36))
     rng = SplitMix64(seed)
-    rng.s = (rng.s + (first * 36) * 0x9E3779B97F4A7C15) & SplitMix64.M
+    rng.skip(first * 36)
     for b in range(batch):
         u = np.array([rng.next() for _ in range(36)])
         out[b] = xn + amp * (2 * u - 1)
@@ -331,6 +335,14 @@ def barrel_roll_running_problem(knots=(12, 21, 42, 15, 20, 15, 100, 125), dt=0.0
         sw.append(sw[-1] + h * dt)
     idx = [0, 1, 2, 3, 4, 5, 5, 5]
     return _br_build(sw, cts, [xf[i] for i in idx], [_BR_WEIGHTS[i] for i in idx], xinit, dt), xinit
+
+
+def barrel_roll_ensemble_x0(batch, seed, xinit, first=0):
+    """Ensemble of initial joint poses around the barrel roll's crouch (+-0.02 rad per joint); problem b draws from stream position b*12."""
+    g = SplitMix64(seed); g.skip(first * 12)
+    x = np.tile(xinit, (batch, 1))
+    x[:, 6:18] += 0.04 * (np.array([g.next() for _ in range(batch * 12)]).reshape(batch, 12) - 0.5)
+    return x
 
 
 def _br_build(sw, cts, tgt, wts, xinit, dt):

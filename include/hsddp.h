@@ -136,7 +136,8 @@ int hsddp_set_initial_condition(hsddp_handle_t *h, const double *x0);
  * per_problem=0 broadcasts one trajectory to the whole batch. Also zeroes K, dU, dX like a fresh Trajectory. */
 int hsddp_set_nominal(hsddp_handle_t *h, int phase, const double *Xbar, const double *Ubar, int per_problem);
 
-/* -- MultiPhaseDDP::solve (MultiPhaseDDP.cpp:216-447).  max_cputime_ms as in the reference. */
+/* -- MultiPhaseDDP::solve (MultiPhaseDDP.cpp:216-447).  max_cputime_ms as in the reference.  opt->MS = 0: single shooting over the whole
+ * horizon (MultiPhaseDDP.cpp:65-68: no shooting nodes, no defects, no linear rollout; dV from the backward sweep). */
 int hsddp_solve(hsddp_handle_t *h, const hsddp_option_t *opt, float max_cputime_ms);
 
 /* -- the public step methods of MultiPhaseDDP (MultiPhaseDDP.h:51-75), exposed for per-iterate parity tests */
@@ -151,6 +152,11 @@ int hsddp_measure_dynamics_feasibility(hsddp_handle_t *h, double *feas /*batch*/
 
 /* -- results */
 int hsddp_get_info(hsddp_handle_t *h, hsddp_info_t *info /* batch */);
+/* MultiPhaseDDP::get_solver_info(cost, dyn_feas, eqn_feas, ineq_feas) (MultiPhaseDDP.h:85, MultiPhaseDDP.cpp:551-559): the four history
+ * buffers of one problem (std::vector<float> in the reference, MultiPhaseDDP.h:133-136): cleared by solve, one entry after the initial
+ * rollout (MultiPhaseDDP.cpp:258-261) and one per inner iteration that ran to its end (:382-385).  Each destination holds `cap`
+ * floats (NULL: skipped); *n receives the number of entries the solver buffered (entries beyond `cap` are not copied). */
+int hsddp_get_history(hsddp_handle_t *h, int problem, int cap, float *cost, float *dyn_feas, float *eqn_feas, float *ineq_feas, int *n);
 /* copies field `f` of `phase` for problems [b0, b0+nb) into dst (host), layout [nb][count][elems] */
 int hsddp_get_field(hsddp_handle_t *h, int phase, int field, int b0, int nb, double *dst);
 /* elems per knot and knot count of a field for a phase (so callers can size dst) */
@@ -161,6 +167,10 @@ float hsddp_get_solve_time_ms(hsddp_handle_t *h);
 /* -- measurement hooks (bench.py): HIP-event time (ms) spent in each kernel family during the last solve
  * and number of launches; names returned as a NUL-separated list. Optional for the CPU backend. */
 int hsddp_get_kernel_times(hsddp_handle_t *h, int max_n, double *ms, long long *launches, char *names, int names_cap);
+/* knots processed by the launches of kernel family `name` ("k_rollout", "k_lq", "k_sweep") since the last reset: launches are masked per
+ * problem, so this is what the algorithmic-bytes figure of the roofline is multiplied with */
+int hsddp_get_kernel_units(hsddp_handle_t *h, const char *name, long long *units);
+int hsddp_reset_kernel_times(hsddp_handle_t *h);
 
 /* -- receding-horizon warm start (MHPCProblem::update, MHPCProblem.cpp:252-397): the phase `dphase` of handle `dst` takes its
  * nominal trajectory from phase `sphase` of handle `src` the way SinglePhase::pop_front / push_back_default shift the

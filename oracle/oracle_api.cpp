@@ -191,6 +191,19 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, abi_f6
     return 0;
 }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, abi_f64*, long long*, char*, int) { return 0; }
+int hsddp_get_kernel_units(hsddp_handle_t*, const char*, long long* units) { if (units) *units = 0; return HSDDP_ENOTSUP; }
+int hsddp_reset_kernel_times(hsddp_handle_t*) { return 0; }
+// MultiPhaseDDP::get_solver_info(cost, dyn_feas, eqn_feas, ineq_feas) (MultiPhaseDDP.cpp:551-559)
+int hsddp_get_history(hsddp_handle_t* h, int problem, int cap, float* cost, float* dyn_feas, float* eqn_feas, float* ineq_feas, int* n) {
+    if (!h || problem < 0 || problem >= h->s.batch || cap < 0 || !n) return HSDDP_EINVAL;
+    const Problem& q = h->s.pb[problem];
+    *n = (int)q.cost_buffer.size();
+    const int m = std::min(*n, cap);
+    const std::vector<float>* src[4] = {&q.cost_buffer, &q.dyn_feas_buffer, &q.eqn_feas_buffer, &q.ineq_feas_buffer};
+    float* dst[4] = {cost, dyn_feas, eqn_feas, ineq_feas};
+    for (int k = 0; k < 4; k++) if (dst[k]) std::copy(src[k]->begin(), src[k]->begin() + m, dst[k]);
+    return 0;
+}
 
 #ifndef ORC_LONG_DOUBLE
 // ---------------------------------------------------------------- model-level probes (tests only)

@@ -69,30 +69,51 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     return 0;
 }
 static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
+// mirrors rollout_chain / k_rollout of cafe-mpc_amd/csrc/hsddp_hip.hip (the emulator cannot include the .hip file: it has no HIP runtime)
+static void emu_chain(hsddp_handle* h, const std::vector<PhaseDev>& ph, WbCore& L, int first, int b, double eps, const OptDev& o, SlotOut so) {
+    for (int pj = first; pj < h->nph && !ph[pj].shooting; pj++) {
+        const PhaseDev& Q = ph[pj]; const PhaseDev* Qn = pj + 1 < h->nph ? &ph[pj + 1] : nullptr; const size_t s0 = (size_t)b * h->nslots + Q.slot0;
+        if (Q.model == HSDDP_MODEL_WB) {
+            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, h->md, b, kq, eps, o.ReB_active, nullptr, so, s0 + kq, h->fail.data(), true);
+            wb_rollout_terminal<64>(L, Q, Qn, h->md, b, eps, o.AL_active, so, s0 + Q.h, true);
+        } else if (Q.model == HSDDP_MODEL_SRB) {
+            SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
+            for (int kq = 0; kq < Q.h; kq++) srb_rollout_knot<64>(Ls, Q, b, kq, eps, o.ReB_active, nullptr, so, s0 + kq, h->fail.data(), true);
+            srb_rollout_terminal<64>(Ls, Q, Qn, b, eps, so, s0 + Q.h, true);
+        } else {
+            HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
+            for (int kq = 0; kq < Q.h; kq++) hkd_rollout_knot<64>(Lh, Q, b, kq, eps, o.ReB_active, nullptr, so, s0 + kq, h->fail.data(), true);
+            hkd_rollout_terminal<64>(Lh, Q, Qn, h->md, b, eps, o.AL_active, so, s0 + Q.h, true);
+        }
+    }
+}
 int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
     OptDev o = to_dev(*opt); SlotOut so{h->cost.data(), h->dsq.data(), h->ming.data(), h->maxh.data()};
-    static WbCore L; static SrbLds Ls; static HkdLds Lh;
+    static_assert(sizeof(WbCore) >= sizeof(SrbLds) && sizeof(WbCore) >= sizeof(HkdLds), "one LDS block serves every model");
+    static WbCore L;
+    std::vector<PhaseDev> ph = h->ph;
+    if (!o.MS) for (auto& q : ph) q.shooting = 0;          // option.MS = false: no shooting nodes anywhere (MultiPhaseDDP.cpp:65-68)
     for (int b = 0; b < h->batch; b++) {
         h->fail[b] = 0;
-        for (int s = 0; s < h->nslots; s++) {
-            int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi]; size_t slot = (size_t)b * h->nslots + s;
-            const PhaseDev* Pn = pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr;
+        if (!ph[0].shooting) {
+            const int n0 = ph[0].n;
+            if (ph[0].model == HSDDP_MODEL_WB) for (int i = 0; i < 36; i++) L.xnext[i] = h->x0[(size_t)b * 36 + i];
+            else for (int i = 0; i < n0; i++) ph[0].Xsim[(size_t)b * (ph[0].h + 1) * n0 + i] = h->x0[(size_t)b * n0 + i];
+            emu_chain(h, ph, L, 0, b, eps, o, so);
+        } else for (int s = 0; s < h->nslots; s++) {
+            int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = ph[pi]; size_t slot = (size_t)b * h->nslots + s;
+            const PhaseDev* Pn = pi + 1 < h->nph ? &ph[pi + 1] : nullptr;
+            if (!P.shooting) continue;
             if (P.model == HSDDP_MODEL_HKD) {
+                HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
                 if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
-                else hkd_rollout_terminal<64>(Lh, P, Pn, h->md, b, eps, o.AL_active, so, slot);
+                else { hkd_rollout_terminal<64>(Lh, P, Pn, h->md, b, eps, o.AL_active, so, slot); emu_chain(h, ph, L, pi + 1, b, eps, o, so); }
             } else if (P.model == HSDDP_MODEL_SRB) {
+                SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
                 if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
-                else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot);
-            } else if (!P.shooting) continue;
-            else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
-            else {
-                wb_rollout_terminal<64>(L, P, pi + 1 < h->nph ? &h->ph[pi + 1] : nullptr, h->md, b, eps, o.AL_active, so, slot);
-                for (int pj = pi + 1; pj < h->nph && !h->ph[pj].shooting; pj++) {
-                    const PhaseDev& Q = h->ph[pj]; const size_t s0 = (size_t)b * h->nslots + Q.slot0;
-                    for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, h->md, b, kq, eps, o.ReB_active, nullptr, so, s0 + kq, h->fail.data(), true);
-                    wb_rollout_terminal<64>(L, Q, pj + 1 < h->nph ? &h->ph[pj + 1] : nullptr, h->md, b, eps, o.AL_active, so, s0 + Q.h, true);
-                }
-            }
+                else { srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot); emu_chain(h, ph, L, pi + 1, b, eps, o, so); }
+            } else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
+            else { wb_rollout_terminal<64>(L, P, Pn, h->md, b, eps, o.AL_active, so, slot); emu_chain(h, ph, L, pi + 1, b, eps, o, so); }
         }
         double c = 0, d = 0; for (int s = 0; s < h->nslots; s++) { c += h->cost[(size_t)b * h->nslots + s]; d += h->dsq[(size_t)b * h->nslots + s]; }
         h->acost[b] = c; h->feas[b] = sqrt(d);
@@ -141,4 +162,7 @@ float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
 int hsddp_export_mpc_command(hsddp_handle_t*, int, int, double, double, const float*, unsigned int*) { return HSDDP_ENOTSUP; }
 int hsddp_warm_start_phase(hsddp_handle_t*, int, hsddp_handle_t*, int, int) { return HSDDP_ENOTSUP; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
+int hsddp_get_kernel_units(hsddp_handle_t*, const char*, long long*) { return HSDDP_ENOTSUP; }
+int hsddp_reset_kernel_times(hsddp_handle_t*) { return 0; }
+int hsddp_get_history(hsddp_handle_t*, int, int, float*, float*, float*, float*, int*) { return HSDDP_ENOTSUP; }
 }

@@ -332,8 +332,7 @@ def test_config4_barrel_roll_running_schedule(hip_lib, oracle_lib, oracle_ld_lib
     B = 1024
     phases, xinit = pkg.problems.barrel_roll_running_problem()
     assert [p["desc"].horizon for p in phases] == [12, 21, 42, 15, 20, 15, 100, 125]
-    g = pkg.problems.SplitMix64(20241220 + 4)
-    x0 = np.tile(xinit, (B, 1)); x0[:, 6:18] += 0.04 * (np.array([g.next() for _ in range(B * 12)]).reshape(B, 12) - 0.5)
+    x0 = pkg.problems.barrel_roll_ensemble_x0(B, 20241220 + 4, xinit)       # the ensemble bench.py --strong draws
     x0[B - 1] = x0[0]; x0[B // 2] = x0[1]
     opt = pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=2)
     s = pkg.MultiPhaseDDP(phases, batch=B)
@@ -349,6 +348,98 @@ def test_config4_barrel_roll_running_schedule(hip_lib, oracle_lib, oracle_ld_lib
     sx = pc.make_exact(pkg, oracle_ld_lib, phases, xs)
     so.solve(opt); sx.solve(opt)
     pc.compare_solve(so, _Sub(s, idx), len(phases), exact=sx)
+
+
+def test_cpp_host_mirror_against_the_hip_library(hip_lib, tmp_path):
+    """The reference-shaped C++ host path executed on the GPU: tests/cpp/host_solve.cpp (C++ problem builder + hsddp::MultiPhaseDDP<double>,
+    the mirror of the reference class) compiled here and linked against libhsddp_hip.so, against the ctypes path on the same problem."""
+    import importlib, subprocess, ctypes
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    exe = tmp_path / "host_solve"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "host_solve.cpp"), "-L", os.path.join(ROOT, "cafe-mpc_amd"), "-lhsddp_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "cafe-mpc_amd"), "-o", str(exe)])
+    opt = builder.load_ddp_setting(os.path.join(tree, "MHPC/settings/ddp_setting.info"))
+    opt.max_AL_iter, opt.max_DDP_iter = 2, 3
+    (tmp_path / "opt.bin").write_bytes(bytes(opt))
+    out = json.loads(subprocess.check_output([str(exe), tree, "bound", str(tmp_path / "opt.bin")], timeout=300))
+    phases, info, cfg = builder.build_from_tree(tree, gait="bound", ubar_mode="zero")
+    s = pkg.Solver(hip_lib, phases, batch=1)
+    for i, p in enumerate(phases):
+        s.set_nominal(i, p["Xbar"], p["Ubar"])
+    s.set_initial_condition(phases[0]["Xbar"][:1]); s.solve(opt)
+    ia = s.info_arrays()
+    assert out["n_iters"] == ia["n_iters"][0] and out["n_ls"] == ia["n_ls_iters"][0] and out["n_reg"] == ia["n_reg_iters"][0] and out["status"] == ia["status"][0]
+    assert out["n_iters"] >= 2
+    assert out["cost"] == ia["actual_cost"][0] and out["feas"] == ia["dyn_feas"][0] and out["tconstr"] == ia["max_tconstr"][0]
+    assert np.array_equal(np.array(out["ubar0"]), s.field(0, "UBAR")[0].ravel())
+    assert np.array_equal(np.array(out["k0"]), s.field(0, "K")[0, 0].T.ravel())
+    hst = s.get_history(0)
+    assert np.array_equal(np.array(out["history_cost"], dtype=np.float32), hst["cost"]) and len(hst["cost"]) >= 2
+
+
+def test_history_buffers_parity(hip_lib, oracle_lib):
+    """get_solver_info(cost, dyn_feas, eqn_feas, ineq_feas) (MultiPhaseDDP.h:85): the float history buffers of GPU and oracle agree entry by
+    entry, one entry after the initial rollout plus one per completed inner iteration; get_*_violation() return the last entries."""
+    phases = pkg.problems.wb_trot_problem(horizons=(8, 8, 8, 8))
+    x0 = pkg.problems.wb_ensemble_x0(3, 20241226)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=3, max_DDP_iter=3)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    ig = sg.info_arrays()
+    for b in range(3):
+        ho, hg = so.get_history(b), sg.get_history(b)
+        assert len(hg["cost"]) == len(ho["cost"]) >= 3
+        for k in ("cost", "dyn_feas", "eqn_feas", "ineq_feas"):
+            assert np.allclose(hg[k], ho[k], rtol=2e-6, atol=1e-9), (b, k, hg[k], ho[k])
+        assert ig["max_tconstr"][b] == float(hg["eqn_feas"][-1]) and ig["max_pconstr"][b] == float(hg["ineq_feas"][-1])
+    sg.solve(opt)      # a second solve clears the buffers first (MultiPhaseDDP.cpp:227-231)
+    assert len(sg.get_history(0)["cost"]) <= 1 + 9
+
+
+@pytest.mark.parametrize("which", ["trot", "mhpc", "hkd"])
+def test_single_shooting_solve_parity(hip_lib, oracle_lib, which):
+    """option.MS = false (MultiPhaseDDP.cpp:65-68): no shooting nodes, every knot takes the simulated state of its predecessor, no defects,
+    no linear rollout (the expected cost change comes from the backward sweep).  One wave per problem walks the whole horizon."""
+    if which == "hkd":
+        phases = pkg.problems.hkd_trot_problem(horizons=(6, 7, 6, 5)); x0 = pkg.problems.hkd_ensemble_x0(3, 11, phases)
+        opt = pkg.problems.hkd_ddp_setting(max_AL_iter=2, max_DDP_iter=3, MS=0)
+    else:
+        phases = pkg.problems.wb_trot_problem(horizons=(7, 6, 5, 6)) if which == "trot" else pkg.problems.mhpc_problem(wb_horizons=(7, 6), srb_horizons=(5, 4))
+        x0 = pkg.problems.wb_ensemble_x0(3, 20241227)
+        opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3, MS=0)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    for s_ in (so, sg):       # per-iterate first: rollout of the nominal, LQ, sweep, rollout of a full step
+        s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.update_nominal_trajectory(); s_.LQ_approximation(opt)
+        assert s_.backward_sweep(0.0).all()
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6)
+    assert np.abs(sg.field(0, "DEFECT")).max() == 0.0
+    for s_ in (so, sg):
+        s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1")
+    so.close(); sg.close()
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
+    assert (sg.info_arrays()["n_iters"] >= 2).all()
+
+
+def test_max_cputime_stops_the_solve(hip_lib, oracle_lib):
+    """max_cputime (the mode the reference's MPC loop always runs in, MHPCLocomotion.cpp:122): a zero budget stops both backends at the
+    first checkpoint (MultiPhaseDDP.cpp:287-291) - one iteration counted, status 2, nominal trajectories those of the initial rollout,
+    one history entry."""
+    phases = pkg.problems.wb_trot_problem(horizons=(5, 5, 5, 5))
+    x0 = pkg.problems.wb_ensemble_x0(2, 20241228)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt, max_cputime_ms=0.0); sg.solve(opt, max_cputime_ms=0.0)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    for k in ("n_iters", "n_ls_iters", "status"):
+        assert np.array_equal(ia[k], ib[k]), k
+    assert (ib["status"] == 2).all() and (ib["n_iters"] == 1).all() and (ib["n_ls_iters"] == 0).all()
+    pc.compare(so, sg, ["XBAR", "UBAR", "X", "U"], len(phases), 1e-8, "timeout")
+    assert len(sg.get_history(0)["cost"]) == 1 == len(so.get_history(0)["cost"])
 
 
 def test_flight_phase_and_four_foot_touchdown(hip_lib, oracle_lib):
@@ -453,8 +544,6 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     phases = pkg.problems.wb_stance_problem(horizon=3)
     s = pkg.Solver(hip_lib, phases, batch=1)
     s.set_nominal(0, phases[0]["Xbar"], phases[0]["Ubar"]); s.set_initial_condition(pkg.problems.wb_nominal_state()[None])
-    with pytest.raises(RuntimeError):
-        s.solve(pkg.mhpc_ddp_setting(MS=0))              # single shooting: HSDDP_ENOTSUP, never a silent fallback
     mixed = pkg.problems.mhpc_problem(wb_horizons=(3, 3), srb_horizons=(2, 2))
     mixed[-1]["desc"].model = pkg.MODEL_HKD          # SRB -> HKD: the reference has no such reset map
     with pytest.raises(RuntimeError):

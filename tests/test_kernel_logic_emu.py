@@ -66,3 +66,23 @@ def test_one_wave_lq_variant_matches_oracle(oracle_lib):
     x0 = pkg.problems.wb_ensemble_x0(2, 20241222)
     so, se = pc.make_pair(pkg, oracle_lib, emu64, phases, x0)
     pc.run_steps(pkg, so, se, phases, pkg.mhpc_ddp_setting(), n_iter=2, rtol=1e-8)
+
+
+@pytest.mark.parametrize("which", ["trot", "mhpc", "hkd"])
+def test_single_shooting_programs_match_oracle(emu_lib, oracle_lib, which):
+    """option.MS = false: the single-shooting chain (one wave walks every phase, SRB / HKD knots included) against the oracle."""
+    if which == "hkd":
+        phases = pkg.problems.hkd_trot_problem(horizons=(3, 4, 3, 3)); x0 = pkg.problems.hkd_ensemble_x0(2, 11, phases)
+        opt = pkg.problems.hkd_ddp_setting(MS=0)
+    else:
+        phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3)) if which == "trot" else pkg.problems.mhpc_problem(wb_horizons=(4, 3), srb_horizons=(3, 2))
+        x0 = pkg.problems.wb_ensemble_x0(2, 20241227); opt = pkg.mhpc_ddp_setting(MS=0)
+    so, se = pc.make_pair(pkg, oracle_lib, emu_lib, phases, x0)
+    for s_ in (so, se):
+        s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.update_nominal_trajectory(); s_.LQ_approximation(opt)
+        assert s_.backward_sweep(0.0).all()
+    pc.compare(so, se, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6)
+    assert np.abs(se.field(0, "DEFECT")).max() == 0.0
+    for s_ in (so, se):
+        s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
+    pc.compare(so, se, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1")

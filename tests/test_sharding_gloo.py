@@ -1,8 +1,8 @@
-"""CPU test of the N>1 path (world_size 2, gloo): the ensemble is sharded into contiguous blocks of problems, each
-rank solves its block with NO data-path collective, and one all-gather of the per-problem result struct puts the
-whole ensemble's results on every rank (bench.py does the same with the HIP backend over RCCL).  The oracle library
-stands in for the solver here only because this container has no GPU; what is under test is the sharding logic:
-x0 stream offsets, result ordering, gathered == unsharded."""
+"""CPU rehearsal of the N>1 path (world_size 2, gloo) through the SAME launcher code bench.py uses (cafe-mpc_amd/launch.py): the parent
+starts the ranks before touching any GPU (maybe_spawn), every rank solves its contiguous block of the ensemble with NO data-path
+collective, and one all-gather of the per-problem result struct puts the whole ensemble's results on every rank.  The oracle library
+stands in for the solver here only because this container has no GPU; what is under test is the launch / sharding / gather logic:
+rank start-up, x0 stream offsets, uneven blocks, result ordering, gathered == unsharded."""
 import os
 import subprocess
 import sys
@@ -15,26 +15,29 @@ from conftest import pkg, ROOT
 WORKER = textwrap.dedent("""
     import ctypes, os, sys
     import numpy as np
-    import torch, torch.distributed as dist
     sys.path.insert(0, sys.argv[1])
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo")
+    launch = pkg.launch
+    TOTAL = int(sys.argv[3])
+    rc = launch.maybe_spawn(2, os.path.abspath(__file__), sys.argv[1:], require_gpus=False)      # the parent: start the two ranks
+    if rc is not None:
+        sys.exit(rc)
+    rank, world, local, dist = launch.init_ranks("gloo")
+    assert world == 2 and dist.get_world_size() == 2
     lib = pkg._abi.bind(ctypes.CDLL(os.path.join(sys.argv[1], "oracle", "liboracle_hsddp.so")))
-    B = 3
+    first, B = launch.shard(TOTAL, world, rank)
     phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
     s = pkg.Solver(lib, phases, batch=B)
     for i, p in enumerate(phases):
         s.set_nominal(i, p["Xbar"], p["Ubar"])
-    s.set_initial_condition(pkg.problems.wb_ensemble_x0(B, 99, first=rank * B))     # this rank's slice of the stream
+    s.set_initial_condition(pkg.problems.wb_ensemble_x0(B, 99, first=first))     # this rank's slice of the stream
     s.solve(pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0))
-    info = s.info_arrays()
-    res = torch.tensor(np.stack([info["actual_cost"], info["dyn_feas"], info["n_iters"].astype(float)], axis=1))
-    out = [torch.empty_like(res) for _ in range(world)]
-    dist.all_gather(out, res)
+    rows = launch.gather_results(dist, launch.result_rows(s.info_arrays()), "cpu")
+    slowest = launch.max_over_ranks(dist, float(rank), "cpu")
     if rank == 0:
-        np.save(sys.argv[2], torch.cat(out).numpy())
+        assert slowest == 1.0
+        np.save(sys.argv[2], rows)
     dist.barrier(); dist.destroy_process_group()
 """)
 
@@ -42,19 +45,18 @@ WORKER = textwrap.dedent("""
 def test_sharded_equals_unsharded(oracle_lib, tmp_path):
     w = tmp_path / "worker.py"; w.write_text(WORKER)
     out = tmp_path / "gathered.npy"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(w), ROOT, str(out)], env=env, timeout=600)
+    TOTAL = 7                                               # uneven split: 4 + 3
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    subprocess.check_call([sys.executable, str(w), ROOT, str(out), str(TOTAL)], env=env, timeout=600)     # no launcher: the worker spawns its ranks itself
     gathered = np.load(out)
-    B = 6
     phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
-    s = pkg.Solver(oracle_lib, phases, batch=B)
+    s = pkg.Solver(oracle_lib, phases, batch=TOTAL)
     for i, p in enumerate(phases):
         s.set_nominal(i, p["Xbar"], p["Ubar"])
-    s.set_initial_condition(pkg.problems.wb_ensemble_x0(B, 99))
+    s.set_initial_condition(pkg.problems.wb_ensemble_x0(TOTAL, 99))
     s.solve(pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0))
-    info = s.info_arrays()
-    ref = np.stack([info["actual_cost"], info["dyn_feas"], info["n_iters"].astype(float)], axis=1)
+    ref = pkg.launch.result_rows(s.info_arrays())
     assert gathered.shape == ref.shape
     assert np.array_equal(gathered, ref)          # same oracle, same inputs -> bit-identical, ordering included
 
@@ -63,3 +65,19 @@ def test_ensemble_stream_offsets():
     a = pkg.problems.wb_ensemble_x0(8, 5)
     b = np.vstack([pkg.problems.wb_ensemble_x0(4, 5, first=0), pkg.problems.wb_ensemble_x0(4, 5, first=4)])
     assert np.array_equal(a, b)
+    xinit = pkg.problems.barrel_roll_states()[0]
+    c = pkg.problems.barrel_roll_ensemble_x0(6, 9, xinit)
+    d = np.vstack([pkg.problems.barrel_roll_ensemble_x0(2, 9, xinit), pkg.problems.barrel_roll_ensemble_x0(4, 9, xinit, first=2)])
+    assert np.array_equal(c, d)
+    assert [pkg.launch.shard(10, 4, r) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a node without two GPUs (this container has none) must fail loudly with a non-zero exit code, never
+    run fewer ranks than asked; a launcher that started a different number of ranks than --gpus is refused as well."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
