@@ -273,7 +273,7 @@ class Solver:
 
     def kernel_units(self):
         out = {}
-        for k in ("k_rollout", "k_lq", "k_sweep"):
+        for k in ("k_rollout", "k_lq", "k_sweep", "k_ls_probe"):
             v = C.c_longlong()
             if self.lib.hsddp_get_kernel_units(self.h, k.encode(), C.byref(v)) == 0:
                 out[k] = int(v.value)

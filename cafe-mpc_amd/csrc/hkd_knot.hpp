@@ -76,16 +76,16 @@ HD double hkd_footreg(PhaseC& P, const double* x, int k) {
 }
 
 template <int NT>
-HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false, bool wr = true) {
     // ss: single shooting (MS = false, MultiPhaseDDP.cpp:65-68): X[k] is the state the previous knot of this wave simulated (Xsim[k]), no defect
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 24, ku = ((size_t)b * h + k) * 24, kk = (size_t)b * h + k;
-    HS_PHASE(NT, if (tid < 24) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; }
+    HS_PHASE(NT, if (tid < 24) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; if (wr) { P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; } }
              for (int i = tid; i < 576; i += NT) L.K[i] = P.K[kk * 576 + i];)
     HS_PHASE(NT, if (tid < 24) {
         double s = 0; for (int j = 0; j < 24; j++) s += L.K[tid + 24 * j] * (L.x[j] - L.xb[j]);
         const double u = P.Ubar[ku + tid] + eps * P.dU[ku + tid] + s;
-        L.u[tid] = u; P.U[ku + tid] = u;
+        L.u[tid] = u; if (wr) P.U[ku + tid] = u;
     })
     HS_PHASE(NT, if (tid == 0) {
         double pxy[8]; for (int l = 0; l < 4; l++) { pxy[2 * l] = L.x[12 + 3 * l]; pxy[2 * l + 1] = L.x[13 + 3 * l]; }
@@ -93,16 +93,16 @@ HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb
     } else if (tid >= 32 && tid < 44) { const int j = tid - 32; L.xn[12 + j] = P.contact[j / 3] ? L.x[12 + j] : L.x[12 + j] + P.dt * L.u[12 + j]; })
     HS_PHASE(NT, if (tid < 24) {
         const double xs = L.xn[tid];
-        P.Xsim[kx + 24 + tid] = xs;
+        if (wr) P.Xsim[kx + 24 + tid] = xs;
         const double d = ss ? 0.0 : xs - (P.Xbar[kx + 24 + tid] + eps * P.dX[kx + 24 + tid]);
-        P.Defect[kx + 24 + tid] = d;
+        if (wr) P.Defect[kx + 24 + tid] = d;
         double dsq = d * d;
-        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 24 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 24 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
+        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 24 + tid] - L.x[tid]; if (wr) { P.Xsim[kx + tid] = x0[(size_t)b * 24 + tid]; P.Defect[kx + tid] = d0; } dsq += d0 * d0; }
         L.red[tid] = dsq; L.tmp[tid] = xs * xs;
     } else if (tid >= 32 && tid < 32 + P.ng) {
         const int c = tid - 32; const size_t gi = kk * P.ng + c;
         const double g = hkd_grf_row(L.u, P.feet[c / 5], c % 5, P.mu);
-        L.gval[c] = g; P.g[gi] = g; L.bar[c] = P.eps[gi] * reb_barrier(g, P.delta[gi]);
+        L.gval[c] = g; if (wr) P.g[gi] = g; L.bar[c] = P.eps[gi] * reb_barrier(g, P.delta[gi]);
     })
     HS_PHASE(NT, if (tid == 0) {
         double lq = 0, lr = 0;
@@ -110,13 +110,13 @@ HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb
         for (int i = 0; i < 24; i++) { const double d = L.u[i] - P.ur[(size_t)k * 24 + i]; lr += d * P.r[i] * d; }
         double l = 0.5 * lq; l += 0.5 * lr; l *= P.dt;
         if (P.w_foot_reg[0] >= 0) { double t = .5 * hkd_footreg(P, L.x, k); t *= P.dt; l += t; }
-        P.lbase[kk] = l;
+        if (wr) P.lbase[kk] = l;
         double ming = 0;
         if (P.ng > 0) {
             double c = 0; for (int i = 0; i < P.ng; i++) { c += L.bar[i]; ming = fmin(ming, L.gval[i]); }
             if (reb_active) l += P.dt * c;
         }
-        P.l[kk] = l;
+        if (wr) P.l[kk] = l;
         double dsq = 0, nsq = 0; for (int i = 0; i < 24; i++) { dsq += L.red[i]; nsq += L.tmp[i]; }
         so.cost[slot] = l; so.dsq[slot] = dsq; so.ming[slot] = ming; so.maxh[slot] = 0.0;
         if (sqrt(nsq) > 1e6 || !(nsq == nsq)) fail_flag[b] = 1;
@@ -126,10 +126,10 @@ HD void hkd_rollout_knot(HkdLds& L, PhaseC& P, int b, int k, double eps, int reb
 // Terminal knot of an HKD phase: terminal cost, touchdown constraint (foot height of the legs about to land), reset map
 // (HKDReset.h:41-76: lift-off -> default joint angles, touchdown -> foot projected on the ground) into the next phase.
 template <int NT>
-HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot, bool ss = false) {
+HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active, SlotOut so, size_t slot, bool ss = false, bool wr = true) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 24;
-    HS_PHASE(NT, if (tid < 24) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
+    HS_PHASE(NT, if (tid < 24) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; if (wr) P.X[kx + tid] = x; })
     HS_PHASE(NT, if (tid < 4 && P.td[tid]) {
         const V3<double> f = hkd_foot<double>(L.x + 3, L.x, L.x + 12 + 3 * tid, tid, md.cpsi_kin, md.spsi_kin);
         L.pf[3 * tid] = f.x; L.pf[3 * tid + 1] = f.y; L.pf[3 * tid + 2] = f.z;
@@ -138,15 +138,15 @@ HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& m
         double s = 0; for (int i = 0; i < 24; i++) { const double d = L.x[i] - P.xr[(size_t)h * 24 + i]; s += d * P.qf[i] * d; }
         double pb = 0.5 * s;
         if (P.w_foot_reg[0] >= 0) pb += 10 * hkd_footreg(P, L.x, h);
-        P.Phibase[b] = pb;
+        if (wr) P.Phibase[b] = pb;
         double maxh = 0, c = 0; int i = 0;
         for (int f = 0; f < 4; f++) if (P.td[f] && P.nt > 0) {
-            const double hh = L.pf[3 * f + 2] - P.ground_height; P.th[(size_t)b * P.nt + i] = hh; maxh = fmax(maxh, fabs(hh));
+            const double hh = L.pf[3 * f + 2] - P.ground_height; if (wr) P.th[(size_t)b * P.nt + i] = hh; maxh = fmax(maxh, fabs(hh));
             const double sg = P.sigma[(size_t)b * P.nt + i], lm = P.lambda[(size_t)b * P.nt + i];
             c += 0.5 * sg * hh * hh; c += lm * hh; i++;
         }
         double Phi = pb; if (al_active && P.nt > 0) Phi += c;
-        P.Phi[b] = Phi;
+        if (wr) P.Phi[b] = Phi;
         so.cost[slot] = Phi; so.ming[slot] = 0.0; so.maxh[slot] = maxh; so.dsq[slot] = 0.0;
     })
     if (Pn == nullptr) return;
@@ -158,9 +158,9 @@ HD void hkd_rollout_terminal(HkdLds& L, PhaseC& P, PhaseC* Pn, const ModelDev& m
             if (P.contact[l] && !P.next_contact[l]) xi = (a == 0) ? 0.0 : (a == 1) ? -0.8 : 1.7;
             if (!P.contact[l] && P.next_contact[l]) xi = (a < 2) ? L.pf[3 * l + a] : 0.0;
         }
-        Pn->Xsim[nx + tid] = xi;
+        if (wr) Pn->Xsim[nx + tid] = xi;
         const double d = (ss || !Pn->shooting) ? 0.0 : xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);     // no shooting node at the start of the next phase: X[0] = x_init
-        Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
+        if (wr) Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < 24; i++) s += L.red[i]; so.dsq[slot] = s; })
 }

@@ -91,6 +91,7 @@ struct ProbState {
     int outer_active, inner_active, ls_active, ls_success, rollout_ok, bs_ok;
     int iter_in, iter_ou;
     int hist_n, push_pending;            // entries in the history buffers; an entry waits for the next control step (see k_eval)
+    int need_commit, pad_;               // batched line search: the trajectories of step ls_eps still have to be written (k_ls_pick)
 };
 
 struct OptDev {

@@ -41,12 +41,13 @@ struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
 #define LQ_ATTR __attribute__((amdgpu_waves_per_eu(LQ_WPE, LQ_WPE)))
 
 // ------------------------------------------------------------------------------------------------ kernels
-enum { MASK_NONE = 0, MASK_LS = 1, MASK_INNER = 2, MASK_OUTER = 3, MASK_LS_OK = 4 };
+enum { MASK_NONE = 0, MASK_LS = 1, MASK_INNER = 2, MASK_OUTER = 3, MASK_LS_OK = 4, MASK_COMMIT = 5 };
 __device__ inline bool masked_out(const ProbState& s, int mask) {
     if (mask == MASK_LS) return !s.ls_active;
     if (mask == MASK_INNER) return !s.inner_active;
     if (mask == MASK_OUTER) return !s.outer_active;
     if (mask == MASK_LS_OK) return !s.ls_success;
+    if (mask == MASK_COMMIT) return !s.need_commit;
     return false;
 }
 
@@ -54,60 +55,119 @@ __device__ inline bool masked_out(const ProbState& s, int mask) {
 // Used for the young phases the receding-horizon update creates (SS_set empty, MHPCProblem.cpp:340-351; first > 0, stops at the next
 // phase with shooting nodes) and for the whole horizon when option.MS is false (MultiPhaseDDP.cpp:65-68; first = 0, descriptors with
 // every shooting flag cleared).  On entry the state to start from is in L.xnext (whole-body phase) / in Xsim[0] of the phase (SRB, HKD).
-__device__ void rollout_chain(WbCore& L, PhaseC* ph, int nph, int first, const ModelDev& md, int b, int nslots, double eps, const OptDev& opt, SlotOut so, int* fail) {
+__device__ __forceinline__ void rollout_chain(WbCore& L, PhaseC* ph, int nph, int first, const ModelDev& md, int b, int nslots, double eps, const OptDev& opt, SlotOut so,
+                                              size_t slot_base, int* fail, bool wr) {
     for (int pj = first; pj < nph && !ph[pj].shooting; pj++) {
-        PhaseC& Q = ph[pj]; PhaseC* Qn = pj + 1 < nph ? &ph[pj + 1] : nullptr; const size_t s0 = (size_t)b * nslots + Q.slot0;
+        PhaseC& Q = ph[pj]; PhaseC* Qn = pj + 1 < nph ? &ph[pj + 1] : nullptr; const size_t s0 = slot_base + Q.slot0;
         if (Q.model == HSDDP_MODEL_WB) {
-            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
-            wb_rollout_terminal<64>(L, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
-        } else if (Q.model == HSDDP_MODEL_SRB) {
+            for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true, wr);
+            wb_rollout_terminal<64>(L, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true, wr);
+        } else if (Q.model == HSDDP_MODEL_SRB) {      // (reads the simulated state back from Xsim: not available to probes, see hsddp_solve)
             SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
-            for (int kq = 0; kq < Q.h; kq++) srb_rollout_knot<64>(Ls, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
-            srb_rollout_terminal<64>(Ls, Q, Qn, b, eps, so, s0 + Q.h, true);
+            for (int kq = 0; kq < Q.h; kq++) srb_rollout_knot<64>(Ls, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true, wr);
+            srb_rollout_terminal<64>(Ls, Q, Qn, b, eps, so, s0 + Q.h, true, wr);
         } else {
             HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
-            for (int kq = 0; kq < Q.h; kq++) hkd_rollout_knot<64>(Lh, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true);
-            hkd_rollout_terminal<64>(Lh, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true);
+            for (int kq = 0; kq < Q.h; kq++) hkd_rollout_knot<64>(Lh, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true, wr);
+            hkd_rollout_terminal<64>(Lh, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true, wr);
         }
     }
 }
 
-__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md,
-                                               double eps, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
+// Step lengths of one launch.  Ordinary launches carry one (eps[0], or the problem's own ls_eps when from_state is set: the commit of a
+// batched line search); a PROBE launch carries the candidates eps[0..n-1] of MultiPhaseDDP::line_search (MultiPhaseDDP.cpp:95-133) that
+// are still to be tried: grid = candidates x problems x slots, candidate c only leaves the per-slot partials of its merit function in
+// slice c of the slot arrays - except candidate `writer` (the last of the search), which also writes the trajectories like an ordinary trial.
+constexpr int MAXCAND = 12;
+struct EpsList { double e[MAXCAND]; int n, writer, from_state; };
+
+__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, int batch, ModelDev md,
+                                               EpsList el, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
-    const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
+    const int per = batch * nslots;
+    const int c = blockIdx.x / per, r = blockIdx.x - c * per;
+    const int b = r / nslots, s = r - b * nslots;
     if (masked_out(st[b], mask)) return;
     if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);     // knots this launch rolls out (measurement only)
     __shared__ WbCore L;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
+    const size_t cbase = (size_t)c * per;                       // slice of candidate c in the slot arrays
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
-    const size_t slot = (size_t)b * nslots + s;
+    const size_t slot_base = cbase + (size_t)b * nslots, slot = slot_base + s;
+    const double eps = el.from_state ? st[b].ls_eps : el.e[c];
+    const bool wr = (c == el.writer);
+    fail += (size_t)c * batch;
+    int chain_first = -1;
     if (!ph[0].shooting) {       // single shooting over the whole horizon (option.MS = false): the wave of slot 0 walks every phase
         if (s != 0) return;
         const int n0 = ph[0].n;
         if (ph[0].model == HSDDP_MODEL_WB) { HS_PHASE(64, if (tid < 36) L.xnext[tid] = x0[(size_t)b * 36 + tid];) }
         else { HS_PHASE(64, if (tid < n0) ph[0].Xsim[(size_t)b * (ph[0].h + 1) * n0 + tid] = x0[(size_t)b * n0 + tid];) }
-        rollout_chain(L, ph, nph, 0, md, b, nslots, eps, opt, so, fail);
-        return;
+        chain_first = 0;
+    } else {
+        if (!P.shooting) return;     // a phase without shooting nodes is rolled sequentially by the wave of its predecessor's terminal knot
+        PhaseC* Pn = pi + 1 < nph ? &ph[pi + 1] : nullptr;
+        if (k == P.h) chain_first = pi + 1;
+        if (P.model == HSDDP_MODEL_HKD) {
+            HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
+            if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail, false, wr);
+            else hkd_rollout_terminal<64>(Lh, P, Pn, md, b, eps, opt.AL_active, so, slot, false, wr);
+        } else if (P.model == HSDDP_MODEL_SRB) {   // reduced-model tail of the MHPC horizon: a few hundred flops per knot, reuses the whole-body LDS block
+            SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
+            if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail, false, wr);
+            else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot, false, wr);
+        } else {
+            if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail, false, wr);
+            else wb_rollout_terminal<64>(L, P, Pn, md, b, eps, opt.AL_active, so, slot, false, wr);
+        }
     }
-    if (!P.shooting) return;     // a phase without shooting nodes is rolled sequentially by the wave of its predecessor's terminal knot
-    if (P.model == HSDDP_MODEL_HKD) {
-        HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
-        if (k < P.h) hkd_rollout_knot<64>(Lh, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-        else { hkd_rollout_terminal<64>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot); rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail); }
-        return;
+    // single-shooting phases from here on (young phases behind a terminal knot, or the whole horizon): ONE call site, one copy of the code
+    if (chain_first >= 0 && chain_first < nph && !ph[chain_first].shooting) rollout_chain(L, ph, nph, chain_first, md, b, nslots, eps, opt, so, slot_base, fail, wr);
+}
+
+// Batched line search, decision step (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:108-131, for the candidates of one probe launch): per
+// problem the candidates are examined IN ORDER - reduction of the slice's partials, merit, Armijo test - exactly as if they had been
+// rolled out one after the other; the first accepted one ends the search.  ls_eps = the step whose trajectories the problem must hold
+// afterwards (the accepted one, else the last one tried: quirk vi); need_commit = those trajectories still have to be written (the
+// launch's writer was another candidate).
+__global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArrays sp, EpsList el, int last_chunk, ProbState* st, OptDev opt, const int* fail, int* counters) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    ProbState& s = st[b];
+    if (!s.ls_active) return;
+    __shared__ double rc[64], rd[64], rg[64], rh[64];
+    __shared__ int accepted;
+    if (tid == 0) accepted = -1;
+    __syncthreads();
+    const size_t per = (size_t)batch * nslots;
+    for (int c = 0; c < el.n; c++) {
+        double cs = 0, d = 0, g = 0, hh = 0;
+        for (int i = tid; i < nslots; i += 64) { const size_t j = c * per + (size_t)b * nslots + i; cs += sp.cost[j]; d += sp.dsq[j]; g = fmin(g, sp.ming[j]); hh = fmax(hh, sp.maxh[j]); }
+        rc[tid] = cs; rd[tid] = d; rg[tid] = g; rh[tid] = hh;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) { if (tid < o) { rc[tid] += rc[tid + o]; rd[tid] += rd[tid + o]; rg[tid] = fmin(rg[tid], rg[tid + o]); rh[tid] = fmax(rh[tid], rh[tid + o]); } __syncthreads(); }
+        if (tid == 0) {
+            const double eps = el.e[c];
+            s.ls_total++;
+            const bool rollout_success = fail[(size_t)c * batch + b] == 0;
+            s.actual_cost = rc[0]; s.max_pconstr = rg[0]; s.max_tconstr = rh[0];
+            s.feas = sqrt(rd[0]);
+            s.merit = s.actual_cost + s.merit_rho * s.feas;
+            const double exp_cost_change = eps * s.dV_1 + 0.5 * eps * eps * s.dV_2;
+            const double exp_merit_change = exp_cost_change - eps * s.merit_rho * s.feas_prev;
+            s.ls_eps = eps;
+            if ((s.merit <= s.merit_prev + opt.gamma * exp_merit_change) && rollout_success) { s.ls_success = 1; s.ls_active = 0; accepted = c; }
+        }
+        __syncthreads();
+        if (accepted >= 0) break;
     }
-    if (P.model == HSDDP_MODEL_SRB) {   // reduced-model tail of the MHPC horizon: a few hundred flops per knot, reuses the whole-body LDS block
-        SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
-        if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-        else { srb_rollout_terminal<64>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b, eps, so, slot); rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail); }
-        return;
-    }
-    if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail);
-    else {
-        wb_rollout_terminal<64>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, eps, opt.AL_active, so, slot);
-        rollout_chain(L, ph, nph, pi + 1, md, b, nslots, eps, opt, so, fail);      // young single-shooting phases behind this one (if any)
+    if (tid == 0) {
+        // trajectories on the device: the writer's (last candidate of the last chunk).  They are the right ones iff the search ends on it.
+        const bool ends_here = accepted >= 0 || last_chunk;
+        const int final_c = accepted >= 0 ? accepted : el.n - 1;
+        s.need_commit = (ends_here && final_c != el.writer) ? 1 : 0;
+        if (s.need_commit) atomicAdd(&counters[3], 1);
+        if (s.ls_active) atomicAdd(&counters[2], 1);
     }
 }
 
@@ -338,7 +398,7 @@ __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa
         if (s.inner_active) { s.actual_cost = cost; s.feas = sqrt(dsq); s.iter_in++; s.iter++; s.ls_success = 0; }
         break;
     case EV_PRE_LS:        // :315-349
-        s.ls_success = 0;
+        s.ls_success = 0; s.need_commit = 0;
         if (s.inner_active) {
             if (!s.bs_ok) { s.status = 1; s.inner_active = 0; s.outer_active = 0; break; }   // bad_solve
             double dV_abs = fabs(s.dV_1 + 0.5 * s.dV_2);
@@ -396,6 +456,8 @@ struct hsddp_handle {
     PhaseDev* d_ph_ss = nullptr;      // the same descriptors with every shooting flag cleared: what option.MS = false rolls out (MultiPhaseDDP.cpp:65-68)
     int *d_slot_phase = nullptr, *d_slot_k = nullptr, *d_fail = nullptr, *d_do_update = nullptr, *d_counters = nullptr, *d_success = nullptr;
     int* h_counters = nullptr;        // pinned
+    SlotArrays sp{}; int sp_cands = 0;       // slot partials of the candidates of a batched line-search launch: [sp_cands][batch][nslots] (allocated on first use)
+    bool probe_ok = true;                    // every phase without shooting nodes is a whole-body phase (their chain keeps its state in LDS: probes need no trajectory store)
     unsigned long long* d_units = nullptr;   // knots processed by k_rollout / k_lq / k_sweep launches since the last reset (measurement)
     float* d_hist = nullptr; int hist_cap = 0;      // history buffers [batch][4][hist_cap]
     unsigned int* d_cmd = nullptr; size_t cmd_words = 0; int* d_cmd_map = nullptr; int cmd_steps = 0; float* d_cmd_status = nullptr;   // export staging (kept across calls)
@@ -468,6 +530,7 @@ void hsddp_destroy(hsddp_handle_t* h) {
     drain_events(h);
     for (void* p : h->allocs) hipFree(p);
     if (h->d_hist) hipFree(h->d_hist);
+    { double* p[4] = {h->sp.cost, h->sp.dsq, h->sp.ming, h->sp.maxh}; for (auto q : p) if (q) hipFree(q); }
     if (h->d_cmd) hipFree(h->d_cmd);
     if (h->d_cmd_map) hipFree(h->d_cmd_map);
     if (h->d_cmd_status) hipFree(h->d_cmd_status);
@@ -522,11 +585,12 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     h->nslots = (int)sp.size();
     if (!rc) rc |= dalloc(h, &h->d_ph, n_phases); if (!rc) rc |= dalloc(h, &h->d_ph_ss, n_phases);
     if (!rc) rc |= dalloc(h, &h->d_slot_phase, sp.size()); if (!rc) rc |= dalloc(h, &h->d_slot_k, sk.size());
-    if (!rc) rc |= dalloc(h, &h->d_fail, B); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
+    if (!rc) rc |= dalloc(h, &h->d_fail, B * MAXCAND); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
     if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n); if (!rc) rc |= dalloc(h, &h->d_units, 8);
     if (!rc) rc |= dalloc(h, &h->sa.cost, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * sp.size());
     if (!rc) rc |= dalloc(h, &h->sa.ming, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * sp.size());
     if (rc) { hsddp_destroy(h); return rc; }
+    for (int i = 0; i < n_phases; i++) if (!phases[i].shooting && phases[i].model != HSDDP_MODEL_WB) h->probe_ok = false;
     std::vector<PhaseDev> ss = h->ph; for (auto& q : ss) q.shooting = 0;
     CREATE_CK(hipMemcpy(h->d_ph, h->ph.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
     CREATE_CK(hipMemcpy(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
@@ -565,14 +629,28 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
 }
 
 // ---- launch helpers
-enum { UNIT_ROLLOUT = 0, UNIT_LQ = 1, UNIT_SWEEP = 2 };
+enum { UNIT_ROLLOUT = 0, UNIT_LQ = 1, UNIT_SWEEP = 2, UNIT_PROBE = 3 };
 static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}; }
-static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask) {
-    Timed t(h, "k_rollout");
-    hipMemsetAsync(h->d_fail, 0, h->batch * sizeof(int), h->stream);
-    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md,
-                       eps, o, h->d_x0, h->sa, h->d_st, mask, h->d_fail, h->d_units + UNIT_ROLLOUT);
+static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotArrays& sa, const OptDev& o, int mask, const char* name, int unit = UNIT_ROLLOUT) {
+    Timed t(h, name);
+    hipMemsetAsync(h->d_fail, 0, (size_t)h->batch * el.n * sizeof(int), h->stream);
+    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k,
+                       h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit);
+}
+static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask, bool eps_from_state = false) {
+    EpsList el{}; el.e[0] = eps; el.n = 1; el.writer = 0; el.from_state = eps_from_state ? 1 : 0;
+    launch_rollout_list(h, el, h->sa, o, mask, "k_rollout");
     if (mask == MASK_NONE) h->cache_valid = true;     // masked launches only refresh problems whose cache was valid already
+}
+// slot arrays for the candidates of a probe launch, grown on demand (never inside an MPC tick once they exist)
+static int ensure_probe_arrays(hsddp_handle* h, int cands) {
+    if (cands <= h->sp_cands) return HSDDP_OK;
+    double** p[4] = {&h->sp.cost, &h->sp.dsq, &h->sp.ming, &h->sp.maxh};
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (auto q : p) { if (*q) HIPCK(hipFree(*q)); *q = nullptr; }
+    h->sp_cands = 0;
+    for (auto q : p) HIPCK(hipMalloc((void**)q, (size_t)cands * h->batch * h->nslots * sizeof(double)));
+    h->sp_cands = cands; return HSDDP_OK;
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_lq");
@@ -630,14 +708,40 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             launch_sweep(h, o, MASK_INNER, 0.0, 1, o.MS ? 1 : 0, 1.0, nullptr);      // (linear rollout only with multiple shooting, MultiPhaseDDP.cpp:326-329)
             if (timeup()) { timed_out = true; break; }
             launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
-            double eps = 1.0;
-            while (eps > 1e-3) {
-                launch_rollout(h, eps, o, MASK_LS);
-                launch_eval(h, EV_LS_TRIAL, o, eps, true, iter_ou);
-                eps *= opt->alpha;
-                // stop issuing trials once no problem is still searching (cheap 16-byte readback)
+            // ---- line search (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:95-133): the step lengths 1, alpha, alpha^2, ... > 1e-3
+            std::vector<double> steps; for (double e = 1.0; e > 1e-3; e *= opt->alpha) { steps.push_back(e); if (!(opt->alpha < 1.0) || steps.size() > 4096) break; }
+            // the full step first, on its own: most searches end here, and it is the one whose trajectories are most likely to stay
+            launch_rollout(h, steps[0], o, MASK_LS);
+            launch_eval(h, EV_LS_TRIAL, o, steps[0], true, iter_ou);
+            hipStreamSynchronize(h->stream);
+            size_t next = 1;
+            if (!(o.MS && h->probe_ok)) {      // single shooting through SRB / HKD phases hands its state over in memory: one trial per launch
+                while (h->h_counters[2] != 0 && next < steps.size()) {
+                    launch_rollout(h, steps[next], o, MASK_LS);
+                    launch_eval(h, EV_LS_TRIAL, o, steps[next], true, iter_ou);
+                    hipStreamSynchronize(h->stream); next++;
+                }
+            }
+            // every remaining candidate of the problems still searching in ONE launch (chunks of MAXCAND): candidates x problems x knots run
+            // side by side as probes, the last candidate of the search also writes its trajectories (what a failed search leaves behind,
+            // quirk vi); k_ls_pick then walks the candidates in order per problem, and only problems that accepted an earlier candidate
+            // need one more rollout of their own step (the commit)
+            while (h->h_counters[2] != 0 && next < steps.size()) {
+                EpsList el{}; el.n = (int)std::min<size_t>(MAXCAND, steps.size() - next);
+                for (int c = 0; c < el.n; c++) el.e[c] = steps[next + c];
+                const bool last_chunk = next + el.n == steps.size();
+                el.writer = last_chunk ? el.n - 1 : -1; el.from_state = 0;
+                { int rc = ensure_probe_arrays(h, el.n); if (rc) return rc; }
+                launch_rollout_list(h, el, h->sp, o, MASK_LS, "k_ls_probe", UNIT_PROBE);
+                {
+                    Timed t(h, "k_eval");
+                    hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
+                    hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters);
+                    hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+                }
                 hipStreamSynchronize(h->stream);
-                if (h->h_counters[2] == 0) break;
+                if (h->h_counters[3] != 0) launch_rollout(h, 0.0, o, MASK_COMMIT, true);      // problems that accepted a probe: their own step, for real
+                next += el.n;
             }
             launch_update_nominal(h, MASK_LS_OK);
             launch_eval(h, EV_POST_LS, o, 0.0, true, iter_ou);
@@ -787,7 +891,7 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double
 // roofline figure of bench.py divides algorithmic bytes by what a launch really processed)
 int hsddp_get_kernel_units(hsddp_handle_t* h, const char* name, long long* units) {
     if (!h || !name || !units) return HSDDP_EINVAL;
-    const int id = !strcmp(name, "k_rollout") ? UNIT_ROLLOUT : !strcmp(name, "k_lq") ? UNIT_LQ : !strcmp(name, "k_sweep") ? UNIT_SWEEP : -1;
+    const int id = !strcmp(name, "k_rollout") ? UNIT_ROLLOUT : !strcmp(name, "k_lq") ? UNIT_LQ : !strcmp(name, "k_sweep") ? UNIT_SWEEP : !strcmp(name, "k_ls_probe") ? UNIT_PROBE : -1;
     if (id < 0) return HSDDP_EINVAL;
     HIPCK(hipSetDevice(h->device));
     unsigned long long v = 0; HIPCK(hipMemcpy(&v, h->d_units + id, sizeof(v), hipMemcpyDeviceToHost));

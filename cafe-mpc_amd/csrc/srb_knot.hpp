@@ -54,25 +54,25 @@ struct SrbLds {
 
 // Rollout of one SRB knot k < h of problem b (SinglePhase::forward_sweep body with the SRB callbacks).
 template <int NT>
-HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb_active, const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false, bool wr = true) {
     // ss: single shooting (MS = false, MultiPhaseDDP.cpp:65-68): X[k] is the state the previous knot of this wave simulated (Xsim[k]), no defect
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 12, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
-    HS_PHASE(NT, if (tid < 12) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; }
+    HS_PHASE(NT, if (tid < 12) { double xb = P.Xbar[kx + tid], x = ss ? P.Xsim[kx + tid] : xb + eps * P.dX[kx + tid]; L.xb[tid] = xb; L.x[tid] = x; if (wr) { P.X[kx + tid] = x; if (ss && k == 0) P.Defect[kx + tid] = 0.0; } }
              for (int i = tid; i < 144; i += NT) L.K[i] = P.K[kk * 144 + i];)
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 12; j++) s += L.K[tid + 12 * j] * (L.x[j] - L.xb[j]);
         const double u = P.Ubar[ku + tid] + eps * P.dU[ku + tid] + s;
-        L.u[tid] = u; P.U[ku + tid] = u;
+        L.u[tid] = u; if (wr) P.U[ku + tid] = u;
     })
     HS_PHASE(NT, if (tid == 0) srb_xdot<double>(L.x, L.u, P.foot_pos + (size_t)k * 12, P.ref_contact + (size_t)k * 4, L.xd);)
     HS_PHASE(NT, if (tid < 12) {
         const double xs = L.x[tid] + L.xd[tid] * P.dt;
-        P.Xsim[kx + 12 + tid] = xs;
+        if (wr) P.Xsim[kx + 12 + tid] = xs;
         const double d = ss ? 0.0 : xs - (P.Xbar[kx + 12 + tid] + eps * P.dX[kx + 12 + tid]);
-        P.Defect[kx + 12 + tid] = d;
+        if (wr) P.Defect[kx + 12 + tid] = d;
         double dsq = d * d;
-        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 12 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 12 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
+        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 12 + tid] - L.x[tid]; if (wr) { P.Xsim[kx + tid] = x0[(size_t)b * 12 + tid]; P.Defect[kx + tid] = d0; } dsq += d0 * d0; }
         L.red[tid] = dsq; L.tmp[tid] = xs * xs;
     })
     HS_PHASE(NT, if (tid == 0) {
@@ -80,14 +80,14 @@ HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb
         for (int i = 0; i < 12; i++) { const double d = L.x[i] - P.xr[(size_t)k * 12 + i]; lq += d * P.q[i] * d; }
         for (int i = 0; i < 12; i++) { const double d = L.u[i] - P.ur[(size_t)k * 12 + i]; lr += d * P.r[i] * d; }
         double l = 0.5 * lq; l += 0.5 * lr; l *= P.dt;
-        P.lbase[kk] = l;
+        if (wr) P.lbase[kk] = l;
         double ming = 0;
         if (P.go_height >= 0) {   // MinimumHeight on the body (MHPCConstraint.cpp:207-250): the only SRB path constraint
             const size_t gi = kk * P.ng + P.go_height; const double g = L.x[2] - P.h_min;
-            P.g[gi] = g; ming = fmin(ming, g);
+            if (wr) P.g[gi] = g; ming = fmin(ming, g);
             if (reb_active) l += P.dt * (P.eps[gi] * reb_barrier(g, P.delta[gi]));
         }
-        P.l[kk] = l;
+        if (wr) P.l[kk] = l;
         double dsq = 0, nsq = 0; for (int i = 0; i < 12; i++) { dsq += L.red[i]; nsq += L.tmp[i]; }
         so.cost[slot] = l; so.dsq[slot] = dsq; so.ming[slot] = ming; so.maxh[slot] = 0.0;
         if (sqrt(nsq) > 1e6 || !(nsq == nsq)) fail_flag[b] = 1;
@@ -96,23 +96,23 @@ HD void srb_rollout_knot(SrbLds& L, PhaseC& P, int b, int k, double eps, int reb
 
 // Terminal knot of an SRB phase: quadratic terminal cost; the reset map to a following SRB phase is the identity.
 template <int NT>
-HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps, SlotOut so, size_t slot, bool ss = false) {
+HD void srb_rollout_terminal(SrbLds& L, PhaseC& P, PhaseC* Pn, int b, double eps, SlotOut so, size_t slot, bool ss = false, bool wr = true) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 12;
-    HS_PHASE(NT, if (tid < 12) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; })
+    HS_PHASE(NT, if (tid < 12) { const double x = ss ? P.Xsim[kx + tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; if (wr) P.X[kx + tid] = x; })
     HS_PHASE(NT, if (tid == 0) {
         double s = 0; for (int i = 0; i < 12; i++) { const double d = L.x[i] - P.xr[(size_t)h * 12 + i]; s += d * P.qf[i] * d; }
         const double Phi = 0.5 * s;
-        P.Phibase[b] = Phi; P.Phi[b] = Phi;
+        if (wr) { P.Phibase[b] = Phi; P.Phi[b] = Phi; }
         so.cost[slot] = Phi; so.ming[slot] = 0.0; so.maxh[slot] = 0.0; so.dsq[slot] = 0.0;
     })
     if (Pn == nullptr) return;
     const size_t nx = ((size_t)b * (Pn->h + 1)) * 12;
     HS_PHASE(NT, if (tid < 12) {
         const double xi = L.x[tid];
-        Pn->Xsim[nx + tid] = xi;
+        if (wr) Pn->Xsim[nx + tid] = xi;
         const double d = (ss || !Pn->shooting) ? 0.0 : xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]);     // no shooting node at the start of the next phase: X[0] = x_init
-        Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
+        if (wr) Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < 12; i++) s += L.red[i]; so.dsq[slot] = s; })
 }

@@ -55,7 +55,9 @@ struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (s
 };
 constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
-#if defined(ROLL_PROF) && !defined(HS_HOST_EMU)
+#if defined(ROLL_PROF_EXTERNAL)
+// (the including file defines RL_STAMP / RL_STAMP0 / KK_STAMP itself: tools/count_instructions.sh places assembler marks there)
+#elif defined(ROLL_PROF) && !defined(HS_HOST_EMU)
 #define RL_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
 #define RL_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
 #else
@@ -65,7 +67,8 @@ struct WbLqLds { WbCore c; WbDeriv d; };
 #if (defined(LQ_PROF) || defined(ROLL_PROF)) && !defined(HS_HOST_EMU)
 __device__ unsigned long long g_lq_prof[16];
 #endif
-#if defined(LQ_PROF) && !defined(HS_HOST_EMU)
+#if defined(LQ_PROF_EXTERNAL)
+#elif defined(LQ_PROF) && !defined(HS_HOST_EMU)
 #define LQ_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
 #define LQ_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
 #else
@@ -468,7 +471,9 @@ HD void store_image(DST dst, int tid, F f) {
 // Rollout of one knot k < h of problem b.   eps: line-search step.
 template <int NT>
 HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, double eps, int reb_active,
-                        const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false) {
+                        const double* x0, SlotOut so, size_t slot, int* fail_flag, bool ss = false, bool wr = true) {
+    // wr = false: a PROBE of the step length eps (one candidate of a batched line-search launch): only the per-slot partials of the merit
+    // function (cost, defect^2, min g, max |h|) and the divergence flag leave the wave, no trajectory / cache store
     // ss: knot of a phase WITHOUT shooting nodes (SS_set empty, a phase the receding-horizon update has just created,
     // MHPCProblem.cpp:340-351): X[k] is the simulated state handed over in L.xnext, X[k+1] = Xsim[k+1], the defect is zero
     const int h = P.h;
@@ -490,7 +495,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         HS_CBAR();
         if (tid < 36) {
             const double xb = va, x = ss ? L.xnext[tid] : xb + eps * vb;
-            L.xb[tid] = xb; L.x[tid] = x; P.X[kx + tid] = x;
+            L.xb[tid] = xb; L.x[tid] = x; if (wr) P.X[kx + tid] = x;
             L.tmp[tid] = vc; L.red[tid] = ss ? 0.0 : vd + eps * ve;
         } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
         else if (tid < 60) L.tmp[tid] = vc;
@@ -500,14 +505,14 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
         double u = L.red[36 + tid] + s;
-        L.u[tid] = u; P.U[ku + tid] = u; L.tau[6 + tid] = u;
+        L.u[tid] = u; if (wr) P.U[ku + tid] = u; L.tau[6 + tid] = u;
     })
     RL_STAMP(0)
     wb_terms<NT>(L, md, true);
     RL_STAMP(1)
     wb_kkt_direct<NT>(L, P.nc, feet_of(P), 0, P.bg_alpha);
     RL_STAMP(2)
-    {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
+    if (wr) {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
         double* kc = P.kc + kk * KC_SIZE;
         HS_PHASE_L(NT,
             store_image<NT, 324, 324>(kc + KC_M, tid, [&](int e, int, int) { return L.M[e]; });
@@ -523,16 +528,16 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     double* S = L.JX;      // scratch (the contact solve is done): [0,36) x-terms | [36,48) u-terms | [48,60) foot terms | [64,100) defect^2 | [100,136) xsim^2
     HS_PHASE(NT, if (tid < 36) {
         const double xs = (tid < 18) ? L.x[tid] + L.x[18 + tid] * P.dt : L.x[tid] + L.qdd[tid - 18] * P.dt;
-        P.Xsim[kx + 36 + tid] = xs;
+        if (wr) P.Xsim[kx + 36 + tid] = xs;
         const double xn = ss ? xs : L.red[tid];
-        const double d = xs - xn; P.Defect[kx + 36 + tid] = d;
-        if (ss) { L.xnext[tid] = xs; if (k == 0) { P.Xsim[kx + tid] = L.x[tid]; P.Defect[kx + tid] = 0.0; } }
+        const double d = xs - xn; if (wr) P.Defect[kx + 36 + tid] = d;
+        if (ss) { L.xnext[tid] = xs; if (k == 0 && wr) { P.Xsim[kx + tid] = L.x[tid]; P.Defect[kx + tid] = 0.0; } }
         double dsq = d * d;
-        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; dsq += d0 * d0; }
+        if (x0 != nullptr && k == 0) { const double d0 = x0[(size_t)b * 36 + tid] - L.x[tid]; if (wr) { P.Xsim[kx + tid] = x0[(size_t)b * 36 + tid]; P.Defect[kx + tid] = d0; } dsq += d0 * d0; }
         S[64 + tid] = dsq; S[100 + tid] = xs * xs;
         const double dx = L.x[tid] - L.tmp[tid]; S[tid] = dx * L.wq[tid] * dx;
     } else if (tid < 48) {
-        const int i = tid - 36; P.Y[kk * 12 + i] = L.grf[i];
+        const int i = tid - 36; if (wr) P.Y[kk * 12 + i] = L.grf[i];
         const double du = L.u[i] - L.tmp[tid]; S[tid] = du * L.wq[36 + i] * du;
     } else if (tid < 52) {     // foot costs of foot f: place regulariser (stance), swing position, swing velocity (MHPCCost.cpp:4-245)
         const int f = tid - 48; const int rc = P.ref_contact[(size_t)k * 4 + f];
@@ -550,7 +555,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     double gmin = 0.0;     // this lane's share of min(0, min_c g_c); the 64 partial minima are folded by one lane below (a minimum does not depend on the order)
     for (int c = tid; c < P.ng; c += NT) {
         const double g = wb_constraint(P, L, c), e = L.gval()[c], dl = L.bar()[c];
-        P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl); gmin = fmin(gmin, g);
+        if (wr) P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl); gmin = fmin(gmin, g);
     }
     if (tid < 64) S[200 + tid] = gmin;)
     RL_STAMP(4)
@@ -562,7 +567,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         double l2 = 0, l3 = 0, l4 = 0;
         for (int f = 0; f < 4; f++) { l2 += S[48 + f]; l3 += S[52 + f]; l4 += S[56 + f]; }
         l += l2; l += l3; l += l4;
-        P.lbase[kk] = l; S[140] = l;
+        if (wr) P.lbase[kk] = l; S[140] = l;
     } else if (tid >= 8 && tid < 13) {    // ReB_cost of constraint object tid-8 (SinglePhase.cpp:394-402)
         int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); const int gI = tid - 8;
         // same order of additions as before, but a fixed trip count (an object has at most 24 constraints): the LDS reads are batched
@@ -583,7 +588,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     HS_PHASE(NT, if (tid == 0) {
         double l = S[140];
         if (reb_active) { int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); for (int gI = 0; gI < nobj; gI++) l += P.dt * S[141 + gI]; }
-        P.l[kk] = l; so.cost[slot] = l;
+        if (wr) P.l[kk] = l; so.cost[slot] = l;
     })
     RL_STAMP(5)
 }
@@ -606,23 +611,23 @@ HD double wb_terminal_cost_base(PhaseC& P, const WbCore& L) {
 // Terminal knot (k = h) of a phase: terminal constraint + cost, then the reset map into the next phase.
 template <int NT>
 HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md, int b, double eps, int al_active,
-                            SlotOut so, size_t slot, bool ss = false) {
+                            SlotOut so, size_t slot, bool ss = false, bool wr = true) {
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + h) * 36;
-    HS_PHASE(NT, if (tid < 36) { double x = ss ? L.xnext[tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; P.X[kx + tid] = x; }
+    HS_PHASE(NT, if (tid < 36) { double x = ss ? L.xnext[tid] : P.Xbar[kx + tid] + eps * P.dX[kx + tid]; L.x[tid] = x; if (wr) P.X[kx + tid] = x; }
              if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0;)
     const bool impact = (Pn != nullptr) && P.has_impact;
     wb_terms<NT>(L, md, impact);
     HS_PHASE(NT, if (tid == 0) {
-        double pb = wb_terminal_cost_base(P, L); P.Phibase[b] = pb;
+        double pb = wb_terminal_cost_base(P, L); if (wr) P.Phibase[b] = pb;
         double maxh = 0, c = 0; int i = 0;
         for (int f = 0; f < 4; f++) if (P.td[f] && P.nt > 0) {
-            double hh = L.fpos[3 * f + 2] - P.ground_height; P.th[(size_t)b * P.nt + i] = hh; maxh = fmax(maxh, fabs(hh));
+            double hh = L.fpos[3 * f + 2] - P.ground_height; if (wr) P.th[(size_t)b * P.nt + i] = hh; maxh = fmax(maxh, fabs(hh));
             double sg = P.sigma[(size_t)b * P.nt + i], lm = P.lambda[(size_t)b * P.nt + i];
             c += 0.5 * sg * hh * hh; c += lm * hh; i++;
         }
         double Phi = pb; if (al_active && P.nt > 0) Phi += c;
-        P.Phi[b] = Phi;
+        if (wr) P.Phi[b] = Phi;
         so.cost[slot] = Phi; so.ming[slot] = 0.0; so.maxh[slot] = maxh; so.dsq[slot] = 0.0;
     })
     if (Pn == nullptr) return;
@@ -637,9 +642,9 @@ HD void wb_rollout_terminal(WbCore& L, PhaseC& P, PhaseC* Pn, const ModelDev& md
         double xi;
         if (nn == 36) xi = (tid < 18) ? L.x[tid] : L.qdd[tid - 18];
         else xi = (tid < 6) ? L.x[tid] : L.qdd[tid - 6];          // StateProjection: x[0:6], x[18:24] (MHPCReset.h:24-26)
-        Pn->Xsim[nx + tid] = xi;
+        if (wr) Pn->Xsim[nx + tid] = xi;
         double d = Pn->shooting ? xi - (Pn->Xbar[nx + tid] + eps * Pn->dX[nx + tid]) : 0.0;     // no shooting node at the start of a young phase: X[0] = x_init
-        Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
+        if (wr) Pn->Defect[nx + tid] = d; L.red[tid] = d * d;
         if (nn == 36) L.xnext[tid] = xi;
     })
     HS_PHASE(NT, if (tid == 0) { double s = 0; for (int i = 0; i < nn; i++) s += L.red[i]; so.dsq[slot] = s; })

@@ -399,7 +399,7 @@ def test_history_buffers_parity(hip_lib, oracle_lib):
 
 
 @pytest.mark.parametrize("which", ["trot", "mhpc", "hkd"])
-def test_single_shooting_solve_parity(hip_lib, oracle_lib, which):
+def test_single_shooting_solve_parity(hip_lib, oracle_lib, oracle_ld_lib, which):
     """option.MS = false (MultiPhaseDDP.cpp:65-68): no shooting nodes, every knot takes the simulated state of its predecessor, no defects,
     no linear rollout (the expected cost change comes from the backward sweep).  One wave per problem walks the whole horizon."""
     if which == "hkd":
@@ -410,18 +410,20 @@ def test_single_shooting_solve_parity(hip_lib, oracle_lib, which):
         x0 = pkg.problems.wb_ensemble_x0(3, 20241227)
         opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3, MS=0)
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    for s_ in (so, sg):       # per-iterate first: rollout of the nominal, LQ, sweep, rollout of a full step
+    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)      # (the single-rigid-body gains reach |K| ~ 4e4: the long-double run arbitrates the absolute 1e-6 there)
+    for s_ in (so, sg, sx):       # per-iterate first: rollout of the nominal, LQ, sweep, rollout of a full step
         s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.update_nominal_trajectory(); s_.LQ_approximation(opt)
         assert s_.backward_sweep(0.0).all()
-    pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6)
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6, exact=sx)
     assert np.abs(sg.field(0, "DEFECT")).max() == 0.0
     for s_ in (so, sg):
         s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
     pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1")
     so.close(); sg.close()
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    so.solve(opt); sg.solve(opt)
-    pc.compare_solve(so, sg, len(phases))
+    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
+    so.solve(opt); sg.solve(opt); sx.solve(opt)
+    pc.compare_solve(so, sg, len(phases), exact=sx)
     assert (sg.info_arrays()["n_iters"] >= 2).all()
 
 
