@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, i
 // rolled out one after the other; the first accepted one ends the search.  ls_eps = the step whose trajectories the problem must hold
 // afterwards (the accepted one, else the last one tried: quirk vi); need_commit = those trajectories still have to be written (the
 // launch's writer was another candidate).
-__global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArrays sp, EpsList el, int last_chunk, ProbState* st, OptDev opt, const int* fail, int* counters) {
+__global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArrays sp, SlotArrays sa, EpsList el, int last_chunk, ProbState* st, OptDev opt, const int* fail, int* counters) {
     const int b = blockIdx.x, tid = threadIdx.x;
     ProbState& s = st[b];
     if (!s.ls_active) return;
@@ -161,12 +161,20 @@ __global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArray
         __syncthreads();
         if (accepted >= 0) break;
     }
+    // trajectories on the device: the writer's (last candidate of the last chunk).  They are the right ones iff the search ends on it; its
+    // per-slot partials then become the problem's current ones (the next iteration's compute_cost / feasibility reduce the base arrays).
+    const bool ends_here = accepted >= 0 || last_chunk;
+    const int final_c = accepted >= 0 ? accepted : el.n - 1;
+    const bool commit = ends_here && final_c != el.writer;
+    if (ends_here && !commit) {
+        for (int i = tid; i < nslots; i += 64) {
+            const size_t j = final_c * per + (size_t)b * nslots + i, d = (size_t)b * nslots + i;
+            sa.cost[d] = sp.cost[j]; sa.dsq[d] = sp.dsq[j]; sa.ming[d] = sp.ming[j]; sa.maxh[d] = sp.maxh[j];
+        }
+    }
     if (tid == 0) {
-        // trajectories on the device: the writer's (last candidate of the last chunk).  They are the right ones iff the search ends on it.
-        const bool ends_here = accepted >= 0 || last_chunk;
-        const int final_c = accepted >= 0 ? accepted : el.n - 1;
-        s.need_commit = (ends_here && final_c != el.writer) ? 1 : 0;
-        if (s.need_commit) atomicAdd(&counters[3], 1);
+        s.need_commit = commit ? 1 : 0;
+        if (commit) atomicAdd(&counters[3], 1);
         if (s.ls_active) atomicAdd(&counters[2], 1);
     }
 }
@@ -736,7 +744,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
                 {
                     Timed t(h, "k_eval");
                     hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
-                    hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters);
+                    hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, h->sa, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters);
                     hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 }
                 hipStreamSynchronize(h->stream);

@@ -204,6 +204,21 @@ def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):
     pc.compare_solve(so, sg, len(phases))
 
 
+def test_fixed_work_past_convergence_line_search_counts(hip_lib, oracle_lib):
+    """The regime bench.py spends most of its steps in: fixed-work mode past convergence, where every line search walks the whole ladder of
+    step lengths and fails (or accepts a tiny step on rounding noise).  The batched search (probe launch + k_ls_pick + commit) must make
+    exactly the decisions the sequential search of the oracle makes: identical line-search counts per problem, same iterates."""
+    phases = pkg.problems.wb_trot_problem(horizons=(20, 20, 20, 20))
+    x0 = pkg.problems.wb_ensemble_x0(6, 20241220 + 3)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=14, cost_thresh=0.0)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt); sg.solve(opt)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    assert (ib["n_iters"] == 14).all() and (ia["n_ls_iters"] > 3 * ia["n_iters"]).any()      # the ladder is being walked
+    assert np.array_equal(ia["n_ls_iters"], ib["n_ls_iters"]), (ia["n_ls_iters"], ib["n_ls_iters"])
+    pc.compare_solve(so, sg, len(phases))
+
+
 def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib, oracle_ld_lib):
     """Ubar = 0 (testMHPCProblem.cpp:70-76): hard start that exercises multi-trial line searches and rejected steps."""
     phases = pkg.problems.wb_stance_problem(horizon=50, ubar_mode="zero")     # BASELINE config 1 literal
