@@ -85,6 +85,53 @@ def latency_probe(pkg, steps):
     return out
 
 
+def mpc_tick_probe(pkg, ticks=24):
+    """The receding-horizon loop the reference runs under an 18 ms budget (MHPCLocomotion.cpp:109-122, testTrajOptInLoop.cpp:85-117): shipped
+    bound gait, 25 whole-body + 10 SRB knots, runtime limits (4 AL x 1 DDP), batch 1, one handle kept across ticks (hsddp_reconfigure).
+    Timed per tick: reconfigure + set_initial_condition + solve + policy export (the ABI calls); the host-side descriptor building is
+    reported separately (here it is the Python mirror of the builder, in the reference it is C++)."""
+    import importlib
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    if not os.path.isdir(tree):
+        return None
+    cfg = builder.load_mhpc_config(tree + "/MHPC/settings/mhpc_config.info")
+    pd = builder.MHPCProblemData(builder.QuadReference(tree + "/Reference/Data/bound/quad_reference.csv"), cfg,
+                                 builder.load_cost_weights(tree + "/" + cfg["costFile"]), builder.load_constraint_params(tree + "/" + cfg["constraintParamFile"]))
+    opt0 = builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")
+    opt_rt = builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")
+    opt_rt.max_AL_iter, opt_rt.max_DDP_iter = opt_rt.max_AL_iter_runtime, opt_rt.max_DDP_iter_runtime
+    phases, info = pd.describe(ubar_mode="gravity_comp")
+    s = pkg.MultiPhaseDDP(phases, batch=1)
+    s.set_initial_condition(info["x0"][None]); s.solve(opt0)
+    nst = int(round(float(cfg["dt_mpc"]) / cfg["dt_wb"]))
+    abi_ms, host_ms, iters = [], [], []
+    lib = pkg.load_hip_library()
+    m0 = None
+    for tick in range(ticks):
+        xg = s.field(0, "XBAR")
+        x0n = np.ascontiguousarray(xg[:, nst] if xg.shape[1] > nst else s.field(1, "XBAR")[:, nst - xg.shape[1] + 1])
+        t0 = time.perf_counter()
+        m = pd.update(); new_phases, inf = pd.describe(ubar_mode="gravity_comp")
+        old_index = {p.get("uid"): i for i, p in enumerate(phases)}
+        src = [old_index[-1] if p.get("uid") == -1 else old_index.get(p.get("uid"), -1) for p in new_phases]
+        shift = [getattr(pd, "srb_steps", 0) if p.get("uid") == -1 else (m[p.get("uid")][0] if p.get("uid") in old_index else 0) for p in new_phases]
+        t1 = time.perf_counter()
+        s.reconfigure(new_phases, src, shift); s.set_initial_condition(x0n); s.solve(opt_rt)
+        s.export_mpc_command(problem=0, n_steps=8, mpc_time=0.01 * tick, dt=cfg["dt_wb"])
+        t2 = time.perf_counter()
+        phases = new_phases
+        if tick == 4:
+            m0 = lib.hsddp_debug_malloc_count()
+        host_ms.append((t1 - t0) * 1e3); abi_ms.append((t2 - t1) * 1e3); iters.append(int(s.info_arrays()["n_iters"][0]))
+    warm = abi_ms[4:]
+    out = {"config": "shipped bound gait, 25 WB + 10 SRB knots, 4 AL x 1 DDP per tick, batch 1, one handle (hsddp_reconfigure)",
+           "budget_ms": 18.0, "ms_per_tick_mean": float(np.mean(warm)), "ms_per_tick_max": float(np.max(warm)), "ddp_iterations_per_tick": float(np.mean(iters[4:])),
+           "device_allocations_in_warm_ticks": int(lib.hsddp_debug_malloc_count() - m0), "host_descriptor_build_ms_python": float(np.mean(host_ms[4:]))}
+    s.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +229,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, args.steps)
         if world == 1 and not args.no_latency and not args.strong:
             line["latency"] = latency_probe(pkg, args.steps)
+            line["latency"]["mpc_tick"] = mpc_tick_probe(pkg)
         print(json.dumps(line), flush=True)
     s.close()
     if dist is not None:

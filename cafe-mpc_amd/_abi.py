@@ -10,7 +10,8 @@ MODEL_WB, MODEL_SRB, MODEL_HKD = 0, 1, 2
 MODEL_DIMS = {MODEL_WB: (36, 12, 12), MODEL_SRB: (12, 12, 0), MODEL_HKD: (24, 24, 0)}
 
 FIELDS = ["X", "XBAR", "XSIM", "DEFECT", "DX", "G", "U", "UBAR", "DU", "QU", "Y", "K", "QUX", "QUU",
-          "A", "B", "C", "D", "L", "LX", "LU", "LY", "LXX", "LUX", "LUU", "LYY", "PHI", "PHIX", "PHIXX", "H0"]
+          "A", "B", "C", "D", "L", "LX", "LU", "LY", "LXX", "LUX", "LUU", "LYY", "PHI", "PHIX", "PHIXX", "H0",
+          "REB_EPS", "REB_DELTA", "AL_SIGMA", "AL_LAMBDA"]
 FIELD_ID = {n: i for i, n in enumerate(FIELDS)}
 
 
@@ -86,7 +87,7 @@ EXPORTS = ["hsddp_create", "hsddp_destroy", "hsddp_set_initial_condition", "hsdd
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
            "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_get_kernel_units", "hsddp_reset_kernel_times", "hsddp_get_history",
-           "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_backend_name"]
+           "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_reconfigure", "hsddp_debug_malloc_count", "hsddp_backend_name"]
 
 
 def bind(lib):
@@ -119,6 +120,9 @@ def bind(lib):
     lib.hsddp_get_history.argtypes = [H, C.c_int, C.c_int, FP, FP, FP, FP, IP]
     lib.hsddp_export_mpc_command.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     lib.hsddp_warm_start_phase.argtypes = [H, C.c_int, H, C.c_int, C.c_int]
+    lib.hsddp_reconfigure.argtypes = [H, C.c_int, C.POINTER(PhaseDesc), IP, IP]
+    lib.hsddp_debug_malloc_count.argtypes = []
+    lib.hsddp_debug_malloc_count.restype = C.c_longlong
     lib.hsddp_backend_name.argtypes = []
     lib.hsddp_backend_name.restype = C.c_char_p
     return lib
@@ -239,6 +243,18 @@ class Solver:
     def warm_start_phase(self, dphase, src, sphase, shift):
         """Receding-horizon shift of one phase's nominal trajectory from another solver of the same backend (device to device)."""
         self._ck(self.lib.hsddp_warm_start_phase(self.h, dphase, src.h if src is not None else None, sphase, shift), "warm_start_phase")
+
+    def reconfigure(self, phases, src_phase, shift):
+        """Receding-horizon update in place (include/hsddp.h hsddp_reconfigure): new phase table, warm start + constraint parameters moved
+        inside the handle, allocations reused."""
+        n = len(phases)
+        arr = (PhaseDesc * n)(*[p["desc"] for p in phases])
+        sp = np.ascontiguousarray(src_phase, dtype=np.int32); sh = np.ascontiguousarray(shift, dtype=np.int32)
+        assert sp.size == n and sh.size == n
+        self._ck(self.lib.hsddp_reconfigure(self.h, n, arr, sp.ctypes.data_as(IP), sh.ctypes.data_as(IP)), "reconfigure")
+        self.phases = phases
+        self.dims = [MODEL_DIMS[p["desc"].model] for p in phases]
+        self.horizons = [p["desc"].horizon for p in phases]
 
     CMD_FIELDS = (("mpc_times", 1, "f"), ("torque", 12, "f"), ("eul", 3, "f"), ("pos", 3, "f"), ("qJ", 12, "f"), ("vWorld", 3, "f"),
                   ("eulrate", 3, "f"), ("qJd", 12, "f"), ("GRF", 12, "f"), ("feedback", 432, "f"), ("Qu", 12, "f"), ("Quu", 144, "f"),

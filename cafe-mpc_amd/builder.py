@@ -332,6 +332,24 @@ def shift_solver(solver_cls, lib, old_solver, old_phases, pd, slot_map, ubar_mod
     return new, phases, info
 
 
+def shift_solver_in_place(solver, old_phases, pd, slot_map, ubar_mode="zero"):
+    """The same receding-horizon step INSIDE the solver's handle (hsddp_reconfigure): new phase table, trajectories and constraint
+    parameters moved device to device, allocations reused (no hipMalloc per tick), solver counters kept.  Returns (phases, info)."""
+    phases, info = pd.describe(ubar_mode=ubar_mode)
+    old_index = {p.get("uid"): i for i, p in enumerate(old_phases)}
+    src, shift = [], []
+    for p in phases:
+        uid = p.get("uid")
+        if uid == -1:
+            src.append(old_index[-1]); shift.append(getattr(pd, "srb_steps", 0))
+        elif uid in old_index:
+            src.append(old_index[uid]); shift.append(slot_map[uid][0])
+        else:
+            src.append(-1); shift.append(0)
+    solver.reconfigure(phases, src, shift)
+    return phases, info
+
+
 # --------------------------------------------------------------------------------------------- HKD-MPC problem
 def load_hkd_constraint_params(path):
     p = load_info(path)

@@ -126,6 +126,10 @@ inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems)
         case HSDDP_F_PHIX: count = 1; elems = n; return P.Phix;
         case HSDDP_F_PHIXX: count = 1; elems = n * n; return P.Phixx;
         case HSDDP_F_H0: count = 1; elems = n * n; return P.H0;
+        case HSDDP_F_REB_EPS: count = h; elems = P.ng; return P.eps;
+        case HSDDP_F_REB_DELTA: count = h; elems = P.ng; return P.delta;
+        case HSDDP_F_AL_SIGMA: count = 1; elems = P.nt; return P.sigma;
+        case HSDDP_F_AL_LAMBDA: count = 1; elems = P.nt; return P.lambda;
         default: count = 0; elems = 0; return nullptr;
     }
 }

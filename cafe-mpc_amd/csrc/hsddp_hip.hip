@@ -25,6 +25,8 @@ using namespace hs;
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return HSDDP_ENODEV; } } while (0)
 
 struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
+static long long g_dev_allocs = 0;      // device allocations made by this library (hsddp_debug_malloc_count: the MPC-tick test watches it)
+#define hipMalloc(...) (++g_dev_allocs, hipMalloc(__VA_ARGS__))
 #ifdef ROLL_WPE
 #define ROLL_ATTR __attribute__((amdgpu_waves_per_eu(ROLL_WPE, ROLL_WPE)))
 #else
@@ -267,7 +269,10 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph_, 
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
 }
 
-// receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase): one workgroup per (problem, destination knot)
+// receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase / hsddp_reconfigure): one workgroup per (problem, destination knot).
+// Trajectories as SinglePhase::pop_front x shift + push_back_default do (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228); the per-knot
+// ReB parameters travel with their knots, a pushed knot copies the last knot's (PathConstraintBase::pop_front / push_back,
+// ConstraintsBase.h:296-306: reset_params() is a no-op, :192); the AL parameters of the terminal constraint stay with the phase (:375).
 __global__ void __launch_bounds__(256) k_warm_start(PhaseDev D, PhaseDev S, int has_src, int shift) {
     const int b = blockIdx.y, k = blockIdx.x, n = D.n, m = D.m, tid = threadIdx.x;
     const size_t dx = ((size_t)b * (D.h + 1) + k) * n, du = ((size_t)b * D.h + k);
@@ -281,7 +286,12 @@ __global__ void __launch_bounds__(256) k_warm_start(PhaseDev D, PhaseDev S, int 
         const bool cs = has_src && ks < S.h; const size_t su = (size_t)b * S.h + ks;
         for (int i = tid; i < m; i += blockDim.x) { const double v = cs ? S.Ubar[su * m + i] : 0.0; D.Ubar[du * m + i] = v; D.U[du * m + i] = v; D.dU[du * m + i] = 0.0; }
         for (int i = tid; i < m * n; i += blockDim.x) D.K[du * m * n + i] = cs ? S.K[su * m * n + i] : 0.0;
+        if (has_src && S.ng == D.ng && S.h > 0) {
+            const size_t sg = (size_t)b * S.h + (ks < S.h ? ks : S.h - 1);
+            for (int i = tid; i < D.ng; i += blockDim.x) { D.eps[du * D.ng + i] = S.eps[sg * S.ng + i]; D.delta[du * D.ng + i] = S.delta[sg * S.ng + i]; }
+        }
     }
+    if (k == 0 && has_src && S.nt == D.nt) for (int i = tid; i < D.nt; i += blockDim.x) { D.sigma[(size_t)b * D.nt + i] = S.sigma[(size_t)b * S.nt + i]; D.lambda[(size_t)b * D.nt + i] = S.lambda[(size_t)b * S.nt + i]; }
 }
 
 // MHPC_Command_lcmt packing (include/hsddp.h): one workgroup per control step, fp64 -> fp32 on the device
@@ -473,7 +483,12 @@ struct hsddp_handle {
     double* d_x0 = nullptr;
     SlotArrays sa{};
     ModelDev md{};
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;        // buffers that live as long as the handle
+    std::vector<void*> gen_allocs;    // phase storage made by hsddp_create (one hipMalloc per array); released by the first hsddp_reconfigure
+    struct Arena { char* base = nullptr; size_t cap = 0, used = 0; } arena[2];      // phase storage of hsddp_reconfigure: the new window is laid out
+    int cur_arena = -1;               //   in one arena while the other (or gen_allocs) still holds the old window; -1: none in use yet
+    std::vector<std::vector<char>> staged;   // host copies of the uploads of the last reconfigure (kept until the next one: async H2D sources)
+    int slots_cap = 0, nph_cap = 0;   // capacity of the slot / descriptor tables
     hipStream_t stream = nullptr;
     float solve_ms = 0;
     bool cache_valid = false;         // every problem has been rolled out since its trajectories were last set from outside: P.kc matches X, U
@@ -537,6 +552,8 @@ void hsddp_destroy(hsddp_handle_t* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     drain_events(h);
     for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->gen_allocs) hipFree(p);
+    for (auto& a : h->arena) if (a.base) hipFree(a.base);
     if (h->d_hist) hipFree(h->d_hist);
     { double* p[4] = {h->sp.cost, h->sp.dsq, h->sp.ming, h->sp.maxh}; for (auto q : p) if (q) hipFree(q); }
     if (h->d_cmd) hipFree(h->d_cmd);
@@ -555,7 +572,7 @@ struct HipMem {
     void* alloc(size_t bytes) {
         void* p = nullptr; bytes = std::max<size_t>(bytes, 8);
         hipError_t e = hipMalloc(&p, bytes); if (e != hipSuccess) { fail(e, "hipMalloc", bytes); return nullptr; }
-        h->allocs.push_back(p);
+        h->gen_allocs.push_back(p);
         e = hipMemset(p, 0, bytes); if (e != hipSuccess) fail(e, "hipMemset", bytes);
         return p;
     }
@@ -591,12 +608,13 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
         for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
     }
     h->nslots = (int)sp.size();
-    if (!rc) rc |= dalloc(h, &h->d_ph, n_phases); if (!rc) rc |= dalloc(h, &h->d_ph_ss, n_phases);
-    if (!rc) rc |= dalloc(h, &h->d_slot_phase, sp.size()); if (!rc) rc |= dalloc(h, &h->d_slot_k, sk.size());
+    h->slots_cap = h->nslots + 16; h->nph_cap = n_phases + 8;      // slack: a receding-horizon update adds or drops a phase (one slot) now and then
+    if (!rc) rc |= dalloc(h, &h->d_ph, h->nph_cap); if (!rc) rc |= dalloc(h, &h->d_ph_ss, h->nph_cap);
+    if (!rc) rc |= dalloc(h, &h->d_slot_phase, h->slots_cap); if (!rc) rc |= dalloc(h, &h->d_slot_k, h->slots_cap);
     if (!rc) rc |= dalloc(h, &h->d_fail, B * MAXCAND); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
     if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n); if (!rc) rc |= dalloc(h, &h->d_units, 8);
-    if (!rc) rc |= dalloc(h, &h->sa.cost, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * sp.size());
-    if (!rc) rc |= dalloc(h, &h->sa.ming, B * sp.size()); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * sp.size());
+    if (!rc) rc |= dalloc(h, &h->sa.cost, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * h->slots_cap);
+    if (!rc) rc |= dalloc(h, &h->sa.ming, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * h->slots_cap);
     if (rc) { hsddp_destroy(h); return rc; }
     for (int i = 0; i < n_phases; i++) if (!phases[i].shooting && phases[i].model != HSDDP_MODEL_WB) h->probe_ok = false;
     std::vector<PhaseDev> ss = h->ph; for (auto& q : ss) q.shooting = 0;
@@ -608,6 +626,92 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     CREATE_CK(hipDeviceSynchronize());
 #undef CREATE_CK
     *out = h; return HSDDP_OK;
+}
+
+// setup_phase memory policies of hsddp_reconfigure: (1) SizeMem walks the layout without touching memory, (2) ArenaMem lays the window out in
+// one arena by bumping a pointer; zero-fill, uploads and replications are queued and issued afterwards on the handle's stream
+struct SizeMem {
+    size_t used = 0;
+    void* alloc(size_t bytes) { bytes = (std::max<size_t>(bytes, 8) + 255) / 256 * 256; void* p = (void*)(uintptr_t)(0x1000 + used); used += bytes; return p; }
+    void upload(void*, const void*, size_t) {}
+    void replicate(void*, size_t, size_t) {}
+};
+struct ArenaMem {
+    hsddp_handle* h; hsddp_handle::Arena* a;
+    struct Up { void* dst; size_t idx, bytes; }; std::vector<Up> ups;
+    struct Rep { void* base; size_t one, count; }; std::vector<Rep> reps;
+    void* alloc(size_t bytes) { bytes = (std::max<size_t>(bytes, 8) + 255) / 256 * 256; if (a->used + bytes > a->cap) return nullptr; void* p = a->base + a->used; a->used += bytes; return p; }
+    void upload(void* dst, const void* src, size_t bytes) { h->staged.emplace_back((const char*)src, (const char*)src + bytes); ups.push_back({dst, h->staged.size() - 1, bytes}); }
+    void replicate(void* base, size_t one, size_t count) { reps.push_back({base, one, count}); }
+    hipError_t flush() {
+        hipError_t e = hipMemsetAsync(a->base, 0, a->used, h->stream); if (e != hipSuccess) return e;
+        for (auto& u : ups) { e = hipMemcpyAsync(u.dst, h->staged[u.idx].data(), u.bytes, hipMemcpyHostToDevice, h->stream); if (e != hipSuccess) return e; }
+        for (auto& r : reps) {
+            size_t have = 1;
+            while (have < r.count) { size_t n = std::min(have, r.count - have); e = hipMemcpyAsync((char*)r.base + have * r.one, r.base, n * r.one, hipMemcpyDeviceToDevice, h->stream); if (e != hipSuccess) return e; have += n; }
+        }
+        return hipSuccess;
+    }
+};
+
+int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t* phases, const int* src_phase, const int* shift) {
+    if (!h || n_phases <= 0 || !phases || !src_phase || !shift) return HSDDP_EINVAL;
+    for (int i = 0; i < n_phases; i++) {
+        if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB && phases[i].model != HSDDP_MODEL_HKD) return HSDDP_EINVAL;
+        if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) return HSDDP_ENOTSUP;
+        if ((!phases[i].shooting && i == 0) || phases[i].horizon <= 0 || shift[i] < 0 || src_phase[i] >= h->nph) return HSDDP_EINVAL;
+        if (src_phase[i] >= 0 && h->ph[src_phase[i]].model != phases[i].model) return HSDDP_EINVAL;
+    }
+    HIPCK(hipSetDevice(h->device));
+    const size_t B = h->batch;
+    // 1. size of the new window, arena to build it in (grown only when the window outgrows it: the first ticks)
+    std::vector<PhaseDev> np(n_phases);
+    std::vector<int> sp, sk;
+    {
+        SizeMem sz;
+        for (int i = 0; i < n_phases; i++) { int rc = setup_phase(sz, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], 0); if (rc) return rc; }
+        const int g = (h->cur_arena == 0) ? 1 : 0;
+        auto& A = h->arena[g];
+        if (sz.used > A.cap) {
+            if (A.base) { HIPCK(hipStreamSynchronize(h->stream)); HIPCK(hipFree(A.base)); A.base = nullptr; A.cap = 0; }
+            const size_t want = sz.used + sz.used / 8;
+            if (hipMalloc((void**)&A.base, want) != hipSuccess) { fprintf(stderr, "[hsddp_hip] hipMalloc(%zu) failed (reconfigure arena)\n", want); return HSDDP_ENOMEM; }
+            A.cap = want;
+        }
+        A.used = 0;
+        h->staged.clear();
+        ArenaMem mem{h, &A};
+        for (int i = 0; i < n_phases; i++) {
+            int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], (int)sp.size()); if (rc) return rc;
+            for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
+        }
+        HIPCK(mem.flush());
+        // 2. tables that depend on the slot / phase count
+        if ((int)sp.size() > h->slots_cap || n_phases > h->nph_cap) {
+            fprintf(stderr, "[hsddp_hip] reconfigure: %zu slots / %d phases exceed the capacity the handle was created with (%d / %d)\n", sp.size(), n_phases, h->slots_cap, h->nph_cap);
+            return HSDDP_ENOTSUP;
+        }
+        // 3. warm start, device to device, old window -> new window (trajectories, ReB parameters, AL parameters)
+        for (int i = 0; i < n_phases; i++) {
+            const bool has = src_phase[i] >= 0;
+            hipLaunchKernelGGL(k_warm_start, dim3(np[i].h + 1, h->batch), dim3(256), 0, h->stream, np[i], has ? h->ph[src_phase[i]] : np[i], has ? 1 : 0, shift[i]);
+        }
+        std::vector<PhaseDev> ss = np; for (auto& q : ss) q.shooting = 0;
+        HIPCK(hipMemcpyAsync(h->d_ph, np.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipMemcpyAsync(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCK(hipStreamSynchronize(h->stream));      // (the host vectors above are the copy sources; the old window is no longer read after this point)
+        // 4. the new window becomes the handle's
+        if (!h->gen_allocs.empty()) { for (void* p : h->gen_allocs) hipFree(p); h->gen_allocs.clear(); }      // storage of hsddp_create: first tick only
+        h->cur_arena = g;
+    }
+    h->ph = np; h->nph = n_phases; h->nslots = (int)sp.size();
+    h->probe_ok = true; for (int i = 0; i < n_phases; i++) if (!phases[i].shooting && phases[i].model != HSDDP_MODEL_WB) h->probe_ok = false;
+    h->cache_valid = false;
+    if (h->d_cmd_status) { hipFree(h->d_cmd_status); h->d_cmd_status = nullptr; }      // sized by the phase count
+    HIPCK(hipGetLastError());
+    return HSDDP_OK;
 }
 
 int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) {
@@ -657,7 +761,7 @@ static int ensure_probe_arrays(hsddp_handle* h, int cands) {
     HIPCK(hipStreamSynchronize(h->stream));
     for (auto q : p) { if (*q) HIPCK(hipFree(*q)); *q = nullptr; }
     h->sp_cands = 0;
-    for (auto q : p) HIPCK(hipMalloc((void**)q, (size_t)cands * h->batch * h->nslots * sizeof(double)));
+    for (auto q : p) HIPCK(hipMalloc((void**)q, (size_t)cands * h->batch * h->slots_cap * sizeof(double)));
     h->sp_cands = cands; return HSDDP_OK;
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
@@ -931,6 +1035,7 @@ int hsddp_debug_sweep_prof(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+long long hsddp_debug_malloc_count(void) { return g_dev_allocs; }
 int hsddp_reset_kernel_times(hsddp_handle_t* h) {
     if (!h) return HSDDP_EINVAL;
     for (auto& v : h->kms) v = 0; for (auto& v : h->kcnt) v = 0;

@@ -117,6 +117,10 @@ enum hsddp_field {
     HSDDP_F_L, HSDDP_F_LX, HSDDP_F_LU, HSDDP_F_LY, HSDDP_F_LXX, HSDDP_F_LUX, HSDDP_F_LUU, HSDDP_F_LYY, /* rcostData */
     HSDDP_F_PHI, HSDDP_F_PHIX, HSDDP_F_PHIXX,                                        /* tcostData   */
     HSDDP_F_H0,                                                                      /* H at knot 0 of the phase, n x n */
+    /* constraint parameters the solver updates between AL iterations and carries across MPC ticks (REB_Param_Struct / AL_Param_Struct,
+     * ConstraintsBase.h:58-86): per knot per path constraint (h x ng; order torque, joint speed, joint, height, GRF), per terminal constraint */
+    HSDDP_F_REB_EPS, HSDDP_F_REB_DELTA,                                              /* h x ng      */
+    HSDDP_F_AL_SIGMA, HSDDP_F_AL_LAMBDA,                                             /* 1 x nt      */
     HSDDP_F_COUNT
 };
 
@@ -171,6 +175,8 @@ int hsddp_get_kernel_times(hsddp_handle_t *h, int max_n, double *ms, long long *
  * problem, so this is what the algorithmic-bytes figure of the roofline is multiplied with */
 int hsddp_get_kernel_units(hsddp_handle_t *h, const char *name, long long *units);
 int hsddp_reset_kernel_times(hsddp_handle_t *h);
+/* number of device allocations the library has made so far in this process (an MPC tick must not add to it once the handle is warm) */
+long long hsddp_debug_malloc_count(void);
 
 /* -- receding-horizon warm start (MHPCProblem::update, MHPCProblem.cpp:252-397): the phase `dphase` of handle `dst` takes its
  * nominal trajectory from phase `sphase` of handle `src` the way SinglePhase::pop_front / push_back_default shift the
@@ -179,6 +185,15 @@ int hsddp_reset_kernel_times(hsddp_handle_t *h);
  *   control k <- Ubar_src[k + shift], K_src[..]   for k + shift <  h_src, else 0
  * sphase < 0: a phase created by the update (zero trajectory).  Same model and batch on both sides. */
 int hsddp_warm_start_phase(hsddp_handle_t *dst, int dphase, hsddp_handle_t *src, int sphase, int shift);
+/* -- the same receding-horizon update INSIDE one handle: the phase table is replaced by `phases`; phase i of the new window continues phase
+ * src_phase[i] of the old one shifted by shift[i] knots (as hsddp_warm_start_phase) or is new (src_phase[i] < 0: zero trajectory, initial
+ * constraint parameters).  Both calls also carry the constraint parameters the way the reference's phase objects do: the per-knot ReB
+ * parameters travel with their knots and a pushed knot copies the last knot's (PathConstraintBase::pop_front / push_back,
+ * ConstraintsBase.h:296-306; reset_params() is a no-op, :192), the AL parameters stay with the phase's terminal constraint (:375).
+ * The handle keeps its solver state (reg_iter_total_ goes on counting like the reference's solver object, MultiPhaseDDP.cpp:218-221) and
+ * reuses its device allocations: after the first ticks a call performs no hipMalloc / hipFree (the 18 ms budget of MHPCLocomotion.cpp:122).
+ * The initial condition is kept; set the new one with hsddp_set_initial_condition. */
+int hsddp_reconfigure(hsddp_handle_t *h, int n_phases, const hsddp_phase_desc_t *phases, const int *src_phase, const int *shift);
 
 /* -- policy export in the field order of lcmtypes/MHPC_Command_lcmt.lcm, filled the way MHPCLocomotion::publish_mpc_cmd does
  * (MHPC/MHPCLocomotion.cpp:190-287): the first n_steps control knots of problem `problem`, walking the whole-body phases in

@@ -123,6 +123,10 @@ static const std::vector<double>* field_ptr(const PhaseDef& P, const Traj& T, in
         case HSDDP_F_PHIXX: count = 1; elems = n * n; return &T.Phixx;
         case HSDDP_F_H0: count = 1; elems = n * n; return &T.H;
         case HSDDP_F_PHI: count = 1; elems = 1; return nullptr;
+        case HSDDP_F_REB_EPS: count = h; elems = (int)P.cons.size(); return &T.eps;
+        case HSDDP_F_REB_DELTA: count = h; elems = (int)P.cons.size(); return &T.delta;
+        case HSDDP_F_AL_SIGMA: count = 1; elems = (int)T.sigma.size(); return &T.sigma;
+        case HSDDP_F_AL_LAMBDA: count = 1; elems = (int)T.lambda.size(); return &T.lambda;
         default: count = 0; elems = 0; return nullptr;
     }
 }
@@ -142,26 +146,48 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, abi
     return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h->s.solve_ms; }
-// SinglePhase::pop_front x shift + push_back_default for the rest (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228)
+// SinglePhase::pop_front x shift + push_back_default for the rest (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228); the ReB parameters
+// travel with their knots and a pushed knot copies the last knot's (PathConstraintBase::pop_front / push_back, ConstraintsBase.h:296-306;
+// reset_params() is a no-op, :192), the AL parameters of the terminal constraint stay with the phase (:375)
+static void warm_start_traj(const PhaseDef& PD, Traj& D, const PhaseDef* PS, const Traj* S, int shift) {
+    const int n = PD.n, m = PD.m, hd = PD.h; const bool has = S != nullptr; const int hs = has ? PS->h : 0;
+    for (int k = 0; k <= hd; k++) for (int i = 0; i < n; i++) {
+        const int ks = k + shift; double v = 0.0;
+        if (has) v = (ks <= hs) ? S->Xbar[(size_t)ks * n + i] : S->X[(size_t)hs * n + i];
+        D.Xbar[(size_t)k * n + i] = v; D.X[(size_t)k * n + i] = v; D.dX[(size_t)k * n + i] = 0.0;
+    }
+    const int ng = (int)PD.cons.size(); const bool pg = has && (int)PS->cons.size() == ng && hs > 0;
+    for (int k = 0; k < hd; k++) {
+        const int ks = k + shift; const bool cs = has && ks < hs;
+        for (int i = 0; i < m; i++) { const double v = cs ? S->Ubar[(size_t)ks * m + i] : 0.0; D.Ubar[(size_t)k * m + i] = v; D.U[(size_t)k * m + i] = v; D.dU[(size_t)k * m + i] = 0.0; }
+        for (int i = 0; i < m * n; i++) D.K[(size_t)k * m * n + i] = cs ? S->K[(size_t)ks * m * n + i] : 0.0;
+        if (pg) { const int kg = ks < hs ? ks : hs - 1; for (int i = 0; i < ng; i++) { D.eps[(size_t)k * ng + i] = S->eps[(size_t)kg * ng + i]; D.delta[(size_t)k * ng + i] = S->delta[(size_t)kg * ng + i]; } }
+    }
+    if (has && S->sigma.size() == D.sigma.size()) { D.sigma = S->sigma; D.lambda = S->lambda; }
+}
 int hsddp_warm_start_phase(hsddp_handle_t* dst, int dphase, hsddp_handle_t* src, int sphase, int shift) {
     if (!dst || dphase < 0 || dphase >= (int)dst->s.ph.size() || shift < 0) return HSDDP_EINVAL;
     const bool has = src != nullptr && sphase >= 0;
     if (has && (sphase >= (int)src->s.ph.size() || src->s.batch != dst->s.batch || src->s.ph[sphase].d.model != dst->s.ph[dphase].d.model)) return HSDDP_EINVAL;
-    const PhaseDef& PD = dst->s.ph[dphase]; const int n = PD.n, m = PD.m, hd = PD.h;
-    for (int b = 0; b < dst->s.batch; b++) {
-        Traj& D = dst->s.pb[b].tr[dphase];
-        const Traj* S = has ? &src->s.pb[b].tr[sphase] : nullptr; const int hs = has ? src->s.ph[sphase].h : 0;
-        for (int k = 0; k <= hd; k++) for (int i = 0; i < n; i++) {
-            const int ks = k + shift; abi_f64 v = 0.0;
-            if (has) v = (ks <= hs) ? S->Xbar[(size_t)ks * n + i] : S->X[(size_t)hs * n + i];
-            D.Xbar[(size_t)k * n + i] = v; D.X[(size_t)k * n + i] = v; D.dX[(size_t)k * n + i] = 0.0;
-        }
-        for (int k = 0; k < hd; k++) {
-            const int ks = k + shift; const bool cs = has && ks < hs;
-            for (int i = 0; i < m; i++) { const abi_f64 v = cs ? S->Ubar[(size_t)ks * m + i] : 0.0; D.Ubar[(size_t)k * m + i] = v; D.U[(size_t)k * m + i] = v; D.dU[(size_t)k * m + i] = 0.0; }
-            for (int i = 0; i < m * n; i++) D.K[(size_t)k * m * n + i] = cs ? S->K[(size_t)ks * m * n + i] : 0.0;
-        }
+    for (int b = 0; b < dst->s.batch; b++)
+        warm_start_traj(dst->s.ph[dphase], dst->s.pb[b].tr[dphase], has ? &src->s.ph[sphase] : nullptr, has ? &src->s.pb[b].tr[sphase] : nullptr, shift);
+    return 0;
+}
+// the same update inside one handle (include/hsddp.h hsddp_reconfigure): the solver object survives, so its counters keep counting (quirk xi)
+int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t* phases, const int* src_phase, const int* shift) {
+    if (!h || n_phases <= 0 || !phases || !src_phase || !shift) return HSDDP_EINVAL;
+    for (int i = 0; i < n_phases; i++) if (src_phase[i] >= (int)h->s.ph.size() || shift[i] < 0 || (src_phase[i] >= 0 && h->s.ph[src_phase[i]].d.model != phases[i].model)) return HSDDP_EINVAL;
+    hsddp_handle* nh = new (std::nothrow) hsddp_handle(); if (!nh) return HSDDP_ENOMEM;
+    hsddp_model_param_t mp; mp.psi_dyn = (abi_f64)h->s.wp.psi_dyn; mp.psi_kin = (abi_f64)h->s.wp.psi_kin;
+    int rc = nh->s.create(n_phases, phases, &mp, h->s.batch);
+    if (rc != HSDDP_OK) { delete nh; return rc; }
+    nh->s.lq_threads = h->s.lq_threads; nh->s.problem_threads = h->s.problem_threads;
+    for (int b = 0; b < h->s.batch; b++) {
+        Problem& q = nh->s.pb[b]; const Problem& o = h->s.pb[b];
+        std::copy(o.x0, o.x0 + 36, q.x0); q.reg_iter_total_ = o.reg_iter_total_;
+        for (int i = 0; i < n_phases; i++) { const bool has = src_phase[i] >= 0; warm_start_traj(nh->s.ph[i], q.tr[i], has ? &h->s.ph[src_phase[i]] : nullptr, has ? &o.tr[src_phase[i]] : nullptr, shift[i]); }
     }
+    std::swap(h->s, nh->s); delete nh;
     return 0;
 }
 // MHPCLocomotion::publish_mpc_cmd (MHPC/MHPCLocomotion.cpp:190-287) restated: field order of MHPC_Command_lcmt.lcm, fp32 casts
@@ -193,6 +219,7 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, abi_f6
 int hsddp_get_kernel_times(hsddp_handle_t*, int, abi_f64*, long long*, char*, int) { return 0; }
 int hsddp_get_kernel_units(hsddp_handle_t*, const char*, long long* units) { if (units) *units = 0; return HSDDP_ENOTSUP; }
 int hsddp_reset_kernel_times(hsddp_handle_t*) { return 0; }
+long long hsddp_debug_malloc_count(void) { return 0; }
 // MultiPhaseDDP::get_solver_info(cost, dyn_feas, eqn_feas, ineq_feas) (MultiPhaseDDP.cpp:551-559)
 int hsddp_get_history(hsddp_handle_t* h, int problem, int cap, float* cost, float* dyn_feas, float* eqn_feas, float* ineq_feas, int* n) {
     if (!h || problem < 0 || problem >= h->s.batch || cap < 0 || !n) return HSDDP_EINVAL;

@@ -161,8 +161,10 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
 float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
 int hsddp_export_mpc_command(hsddp_handle_t*, int, int, double, double, const float*, unsigned int*) { return HSDDP_ENOTSUP; }
 int hsddp_warm_start_phase(hsddp_handle_t*, int, hsddp_handle_t*, int, int) { return HSDDP_ENOTSUP; }
+int hsddp_reconfigure(hsddp_handle_t*, int, const hsddp_phase_desc_t*, const int*, const int*) { return HSDDP_ENOTSUP; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
 int hsddp_get_kernel_units(hsddp_handle_t*, const char*, long long*) { return HSDDP_ENOTSUP; }
 int hsddp_reset_kernel_times(hsddp_handle_t*) { return 0; }
+long long hsddp_debug_malloc_count(void) { return 0; }
 int hsddp_get_history(hsddp_handle_t*, int, int, float*, float*, float*, float*, int*) { return HSDDP_ENOTSUP; }
 }

@@ -122,3 +122,53 @@ def test_cpp_builder_matches_python_mirror(tmp_path, gait):
             import ctypes
             wb = [bytes(d.q), bytes(d.r), bytes(d.qf), ctypes.string_at(ctypes.addressof(d.reb_torque), 4 * ctypes.sizeof(d.reb_torque)), bytes(d.al_td)]
             assert str(_fnv(wb)) == c["whash"]
+
+
+def _mpc_setup():
+    cfg = builder.load_mhpc_config(TREE + "/MHPC/settings/mhpc_config.info")
+    pd = builder.MHPCProblemData(builder.QuadReference(TREE + "/Reference/Data/bound/quad_reference.csv"), cfg,
+                                 builder.load_cost_weights(TREE + "/" + cfg["costFile"]), builder.load_constraint_params(TREE + "/" + cfg["constraintParamFile"]))
+    opt0 = builder.load_ddp_setting(TREE + "/MHPC/settings/ddp_setting.info")
+    opt_rt = builder.load_ddp_setting(TREE + "/MHPC/settings/ddp_setting.info")
+    opt_rt.max_AL_iter, opt_rt.max_DDP_iter = opt_rt.max_AL_iter_runtime, opt_rt.max_DDP_iter_runtime       # MHPCLocomotion.cpp:113-115
+    return cfg, pd, opt0, opt_rt
+
+
+def test_constraint_parameters_survive_the_receding_horizon_shift(oracle_lib):
+    """The reference's phase objects keep their constraint parameters across MPC ticks: per-knot ReB parameters are popped / pushed with
+    their knots (a pushed knot copies the last knot's, ConstraintsBase.h:296-306, reset_params() is a no-op :192), AL parameters stay
+    with the phase.  The first solve (up to 20 AL iterations of update_params) changes them; the shifted window must start from the
+    UPDATED values, whichever of the two ABI routes moves it (new handle + hsddp_warm_start_phase, or hsddp_reconfigure in place)."""
+    cfg, pd, opt0, opt_rt = _mpc_setup()
+    phases, info = pd.describe(ubar_mode="gravity_comp")
+    x0 = info["x0"][None]
+    s = pc.make_pair(pkg, oracle_lib, oracle_lib, phases, x0)[0]
+    s2 = pc.make_pair(pkg, oracle_lib, oracle_lib, phases, x0)[0]
+    s.solve(opt0); s2.solve(opt0)
+    eps0 = [s.field(i, "REB_EPS") for i in range(len(phases))]
+    init = [p["desc"].reb_torque.eps for p in phases]
+    changed = any(e.size and not np.allclose(e, e.flat[0]) for e in eps0) or any(s.field(i, "AL_SIGMA").size and (s.field(i, "AL_SIGMA") != phases[i]["desc"].al_td.sigma).any() for i in range(len(phases)))
+    assert changed, "the first solve must have updated ReB or AL parameters for this test to mean anything"
+    m = pd.update()
+    nst = int(round(float(cfg["dt_mpc"]) / cfg["dt_wb"]))
+    x0n = s.field(0, "XBAR")[:, nst]
+    old_phases = phases
+    sa, pha, infa = builder.shift_solver(pkg.Solver, oracle_lib, s, old_phases, pd, m)          # route 1: new handle
+    phb, infb = builder.shift_solver_in_place(s2, old_phases, pd, m)                              # route 2: in place
+    uid_old = {p.get("uid"): i for i, p in enumerate(old_phases)}
+    for i, p in enumerate(pha):
+        for f in ("REB_EPS", "REB_DELTA", "AL_SIGMA", "AL_LAMBDA", "XBAR", "UBAR", "K"):
+            assert np.array_equal(sa.field(i, f), s2.field(i, f)), (i, f)
+        j = uid_old.get(p.get("uid"))
+        if j is not None and p.get("uid") != -1 and eps0[j].size:
+            sh = m[p.get("uid")][0]
+            got = sa.field(i, "REB_EPS")[0]; src = eps0[j][0]
+            for k in range(got.shape[0]):
+                assert np.array_equal(got[k], src[min(k + sh, src.shape[0] - 1)]), (i, k)
+    for q in (sa, s2):
+        q.set_initial_condition(np.ascontiguousarray(x0n)); q.solve(opt_rt)
+    ia, ib = sa.info_arrays(), s2.info_arrays()
+    for k in ("actual_cost", "dyn_feas", "n_iters", "n_ls_iters"):
+        assert np.array_equal(ia[k], ib[k]), k
+    # the handle that was reconfigured kept counting regularisation iterations (quirk xi); the new handle started from zero
+    assert (ib["n_reg_iters"] >= ia["n_reg_iters"]).all()

@@ -143,9 +143,10 @@ def test_full_solve_parity_hkd_shipped_gait(hip_lib, oracle_lib, oracle_ld_lib):
 
 
 def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
-    """The MPC loop of testTrajOptInLoop.cpp:85-117 in shape: solve, then per tick MHPCProblem::update (phase table shift incl. the
-    young single-shooting phases), warm start moved device to device (hsddp_warm_start_phase), runtime iteration limits.  GPU and
-    oracle run the same loop; every tick's solve must agree."""
+    """The MPC loop of testTrajOptInLoop.cpp:85-117 in shape: solve, then per tick MHPCProblem::update (phase table shift incl. the young
+    single-shooting phases) moved INSIDE the handle (hsddp_reconfigure: trajectories, ReB / AL parameters, solver counters carried; no
+    device allocation once the handle is warm), runtime iteration limits.  GPU and oracle run the same loop, every tick's solve must agree;
+    the two-handle route (hsddp_warm_start_phase) must give the GPU the same window bit for bit."""
     import importlib, os
     from conftest import ROOT
     builder = importlib.import_module(pkg.__name__ + ".builder")
@@ -159,23 +160,36 @@ def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
     phases, info = pd.describe(ubar_mode="gravity_comp")
     x0 = np.vstack([info["x0"], info["x0"] + 0.005 * (pkg.problems.wb_ensemble_x0(1, 3)[0] - pkg.problems.wb_nominal_state())])
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    so.solve(opt0); sg.solve(opt0)
-    pc.compare_solve(so, sg, len(phases), rtol=1e-5)
+    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
+    for s_ in (so, sg, sx):
+        s_.solve(opt0)
+    pc.compare_solve(so, sg, len(phases), exact=sx)
     seen_young = False
-    for tick in range(1, 8):
+    mallocs = []
+    for tick in range(1, 9):
         m = pd.update()
         nst = int(round(float(cfg["dt_mpc"]) / cfg["dt_wb"]))
-        xg = sg.field(0, "XBAR")        # predicted state after one MPC step = next initial condition (same vector for both backends)
-        x0n = xg[:, nst] if xg.shape[1] > nst else sg.field(1, "XBAR")[:, nst - xg.shape[1] + 1]
-        so2, ph2, inf2 = builder.shift_solver(pkg.Solver, oracle_lib, so, phases, pd, m)
-        sg2, _, _ = builder.shift_solver(pkg.Solver, hip_lib, sg, phases, pd, m)
+        xg = sg.field(0, "XBAR")        # predicted state after one MPC step = next initial condition (same vector for every backend)
+        x0n = np.ascontiguousarray(xg[:, nst] if xg.shape[1] > nst else sg.field(1, "XBAR")[:, nst - xg.shape[1] + 1])
+        if tick == 2:                   # the two-handle route on the GPU, for comparison with the in-place one below
+            s2, ph2, _ = builder.shift_solver(pkg.Solver, hip_lib, sg, phases, pd, m)
+        old_phases = phases
+        for s_ in (so, sx):
+            builder.shift_solver_in_place(s_, old_phases, pd, m)
+        phases, inf2 = builder.shift_solver_in_place(sg, old_phases, pd, m)
+        if tick == 2:
+            for i in range(len(phases)):
+                for f in ("XBAR", "UBAR", "K", "REB_EPS", "REB_DELTA", "AL_SIGMA", "AL_LAMBDA"):
+                    assert np.array_equal(s2.field(i, f), sg.field(i, f)), (i, f)
+            s2.close()
         seen_young |= 0 in inf2["shooting"]
-        for s2 in (so2, sg2):
-            s2.set_initial_condition(np.ascontiguousarray(x0n)); s2.solve(opt_rt)
-        pc.compare_solve(so2, sg2, len(ph2), rtol=1e-5)
+        for s_ in (so, sg, sx):
+            s_.set_initial_condition(x0n); s_.solve(opt_rt)
+        pc.compare_solve(so, sg, len(phases), exact=sx)
         assert sum(inf2["horizons"]) == 25
-        so.close(); sg.close(); so, sg, phases = so2, sg2, ph2
+        mallocs.append(hip_lib.hsddp_debug_malloc_count())
     assert seen_young
+    assert mallocs[3:] == [mallocs[3]] * len(mallocs[3:]), mallocs     # a warm handle runs its ticks without device allocations
 
 
 def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib, oracle_ld_lib):
