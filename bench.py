@@ -33,6 +33,14 @@ ALG_BYTES = {
     "k_rollout": (528 + 133 + 69) * 8,      # K1 per line-search trial
     "k_ls_probe": (528 + 133 + 69) * 8,     # K1 per candidate step of a batched line-search launch
 }
+# the same for the kinodynamic model (HKD 24/24/0, BASELINE config 5): elements per knot x bytes per element of each stream.  LQ: reads x, u, refs
+# (~100 fp64), writes A, B, lxx, luu, lx, lu (2352 record elements); sweep: Riccati reads the record + Defect and writes K, dU, Qu, Quu, Qux, G
+# (1800 fp64), the linear rollout reads the record again + K, dU, Defect and writes dX; rollout: K, Xbar, dX, Ubar, dU + outputs (672 + 117 fp64)
+def hkd_alg_bytes(rec_bytes):
+    return {"k_lq": 100 * 8 + 2352 * rec_bytes, "k_sweep": 2 * 2352 * rec_bytes + (24 + 1800 + 576 + 24 + 24 + 24) * 8,
+            "k_rollout": (672 + 117) * 8, "k_ls_probe": (672 + 117) * 8}
+
+
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 METRIC = "DDP iterations/sec, Mini-Cheetah WB N=200, batch=4096; 1/2/4/8 GPU"
 
@@ -139,6 +147,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="problems per GPU (weak, default 4096) / in total (--strong, default 8192)")
     ap.add_argument("--strong", action="store_true", help="fixed total work: config 4 (barrel roll, 8 phases, N=350), 8192 problems split over the ranks")
+    ap.add_argument("--hkd", choices=["f32", "f64"], default=None, help="BASELINE config 5 instead: HKD 24/24/0, N=200 bound-gait schedule, 16384 problems per GPU, "
+                                                                             "on an fp32 handle (fp32 LQ records + fp32 MFMA sweep) or an fp64 one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -165,6 +175,17 @@ def main():
         opt_fn = lambda k: pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=k, cost_thresh=0.0)   # noqa: E731
         workload = ("barrel roll with running lead-out, WB 36/12/12, 8 hybrid phases / N=350: 1111(12) 0101(21) 0000(42) 1111(15) 0000(20) "
                     "1111(15) 0101(100) 1010(125), dt=0.01, zero-torque start, ensemble of initial joint poses, fixed-work mode")
+    elif args.hkd:
+        B = args.batch or 16384
+        total = B * world; first = rank * B
+        seed = 20241220 + 5
+        phases_fn = pkg.problems.hkd_bound_problem
+        hkd_ref = pkg.problems.hkd_bound_problem()
+        x0_fn = lambda n, first=0: pkg.problems.hkd_ensemble_x0(n, seed, hkd_ref, first=first)   # noqa: E731
+        opt_fn = lambda k: pkg.problems.hkd_ddp_setting(max_AL_iter=1, max_DDP_iter=k, cost_thresh=0.0)   # noqa: E731
+        workload = ("HKD 24/24/0 (hybrid kinodynamic), N=200 in the contact pattern of the shipped bound gait: 1111(6), then 1100(10) 0000(10) 0011(10) "
+                    "0000(10) repeating (21 phases), dt=0.01, ensemble of initial body states, fixed-work mode; " +
+                    ("fp32 handle: fp32 LQ records, Riccati sweep + linear rollout on v_mfma_f32_16x16x4_f32, rollouts / LQ knots / merit in fp64" if args.hkd == "f32" else "fp64 handle"))
     else:
         B = args.batch or 4096
         total = B * world; first = rank * B
@@ -176,8 +197,12 @@ def main():
                     "fixed-work mode (max_AL_iter=1, cost_thresh=0)")
     x0 = x0_fn(B, first)
 
+    prec = pkg.PREC_F32 if args.hkd == "f32" else pkg.PREC_F64
+    alg_bytes = hkd_alg_bytes(4 if args.hkd == "f32" else 8) if args.hkd else ALG_BYTES
+    alg_total = sum(alg_bytes[k] for k in ("k_lq", "k_sweep", "k_rollout"))
+
     def run(iters):
-        s = pkg.MultiPhaseDDP(phases_fn(), batch=B, device=local)
+        s = pkg.MultiPhaseDDP(phases_fn(), batch=B, device=local, precision=prec)
         s.set_initial_condition(x0)
         return s, opt_fn(iters)
 
@@ -202,12 +227,12 @@ def main():
     if rank == 0:
         kt = s.kernel_times()
         knots = sum(p["desc"].horizon for p in s.phases)
-        dom = max((k for k in kt if k in ALG_BYTES), key=lambda k: kt[k][0], default=None)
+        dom = max((k for k in kt if k in alg_bytes), key=lambda k: kt[k][0], default=None)
         roof = None
         if dom:
             ms, n = kt[dom]
             units = s.kernel_units().get(dom)             # knots (x candidate steps) the launches of this kernel family processed
-            per_launch_bytes = ALG_BYTES[dom] * (units / n if units else knots * B)
+            per_launch_bytes = alg_bytes[dom] * (units / n if units else knots * B)
             achieved = per_launch_bytes / (ms / n * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -216,18 +241,18 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
                     "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()},
-                    "whole_iteration": {"alg_bytes_per_knot_iteration": 119280, "achieved_GBs": 119280.0 * knots * iters_done / dt / 1e9 / world,
-                                        "frac_of_peak": 119280.0 * knots * iters_done / dt / 1e9 / world / HBM_PEAK_GBS}}
+                    "whole_iteration": {"alg_bytes_per_knot_iteration": alg_total, "achieved_GBs": alg_total * knots * iters_done / dt / 1e9 / world,
+                                        "frac_of_peak": alg_total * knots * iters_done / dt / 1e9 / world / HBM_PEAK_GBS}}
         line = {"metric": METRIC, "value": iters_done / dt, "unit": "DDP iterations/s",
                 "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32" if args.hkd == "f32" else "f64", "data": "synthetic",
                 "config": {"workload": workload, "batch_per_gpu": B, "global_batch": total,
                            "parallelism": f"ensemble-sharded x{world}", "n_status_ok": int((res_all[:, 7] == 0).sum()),
                            "mean_ls_trials_per_iter": float(res_all[:, 5].sum() / max(iters_done, 1))},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, args.steps)
-        if world == 1 and not args.no_latency and not args.strong:
+        if world == 1 and not args.no_latency and not args.strong and not args.hkd:
             line["latency"] = latency_probe(pkg, args.steps)
             line["latency"]["mpc_tick"] = mpc_tick_probe(pkg)
         print(json.dumps(line), flush=True)

@@ -9,7 +9,7 @@ import ctypes as _C
 import os as _os
 
 from . import _abi
-from ._abi import Option, mhpc_ddp_setting, Solver, MODEL_WB, MODEL_SRB, MODEL_HKD  # noqa: F401
+from ._abi import Option, mhpc_ddp_setting, Solver, MODEL_WB, MODEL_SRB, MODEL_HKD, PREC_F64, PREC_F32  # noqa: F401
 from . import problems  # noqa: F401
 from . import launch  # noqa: F401
 
@@ -42,6 +42,7 @@ class MultiPhaseDDP(Solver):
     """
 
     def __init__(self, phases, batch=1, device=0, **kw):
+        # precision=PREC_F32: fp32 LQ records + fp32 matrix-core sweep (kinodynamic / SRB phases), see include/hsddp.h hsddp_create_ex
         super().__init__(load_hip_library(), phases, batch=batch, device=device, **kw)
         for i, p in enumerate(phases):
             self.set_nominal(i, p["Xbar"], p["Ubar"])

@@ -82,7 +82,9 @@ class Info(C.Structure):
                 ("n_iters", C.c_int), ("n_ls_iters", C.c_int), ("n_reg_iters", C.c_int), ("status", C.c_int)]
 
 
-EXPORTS = ["hsddp_create", "hsddp_destroy", "hsddp_set_initial_condition", "hsddp_set_nominal", "hsddp_solve",
+PREC_F64, PREC_F32 = 0, 1
+
+EXPORTS = ["hsddp_create", "hsddp_create_ex", "hsddp_precision", "hsddp_destroy", "hsddp_set_initial_condition", "hsddp_set_nominal", "hsddp_solve",
            "hsddp_hybrid_rollout", "hsddp_compute_cost", "hsddp_LQ_approximation", "hsddp_backward_sweep",
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
@@ -95,6 +97,8 @@ def bind(lib):
     H = C.c_void_p
     OP = C.POINTER(Option)
     lib.hsddp_create.argtypes = [C.POINTER(H), C.c_int, C.POINTER(PhaseDesc), C.POINTER(ModelParam), C.c_int, C.c_int]
+    lib.hsddp_create_ex.argtypes = [C.POINTER(H), C.c_int, C.POINTER(PhaseDesc), C.POINTER(ModelParam), C.c_int, C.c_int, C.c_int]
+    lib.hsddp_precision.argtypes = [H]
     lib.hsddp_destroy.argtypes = [H]
     lib.hsddp_destroy.restype = None
     lib.hsddp_set_initial_condition.argtypes = [H, DP]
@@ -139,7 +143,7 @@ class Solver:
     the constructor (descriptors instead of closures), then set_initial_condition / solve / get_*.
     """
 
-    def __init__(self, lib, phases, batch=1, device=0, psi_dyn=3.1415, psi_kin=np.pi):
+    def __init__(self, lib, phases, batch=1, device=0, psi_dyn=3.1415, psi_kin=np.pi, precision=PREC_F64):
         self.lib = lib
         self.phases = phases            # list of dicts produced by problems.py (keeps numpy buffers alive)
         self.batch = batch
@@ -147,9 +151,10 @@ class Solver:
         arr = (PhaseDesc * n)(*[p["desc"] for p in phases])
         mp = ModelParam(psi_dyn, psi_kin)
         self.h = C.c_void_p()
-        rc = lib.hsddp_create(C.byref(self.h), n, arr, C.byref(mp), batch, device)
+        rc = lib.hsddp_create_ex(C.byref(self.h), n, arr, C.byref(mp), batch, device, precision)
         if rc != 0:
-            raise RuntimeError(f"hsddp_create failed rc={rc}")
+            raise RuntimeError(f"hsddp_create_ex failed rc={rc}")
+        self.precision = precision
         self.dims = [MODEL_DIMS[p["desc"].model] for p in phases]
         self.horizons = [p["desc"].horizon for p in phases]
 

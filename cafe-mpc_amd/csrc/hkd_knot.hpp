@@ -197,7 +197,7 @@ HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
             a = (r == c) ? 1.0 : 0.0;
             bb = (r == c && !P.contact[(r - 12) / 3]) ? dt : 0.0;
         }
-        P.A[kk * P.rs + e] = a; P.B[kk * P.rs + e] = bb;
+        rec_put(P, kk, P.oA + e, a); rec_put(P, kk, P.oB + e, bb);
         // lxx: tracking diagonal + foot-placement regulariser dprel_dx' Q dprel_dx (HKDCost.cpp:22-35)
         double q = (r == c) ? dt * P.q[r] : 0.0;
         if (fr != 0.0) {
@@ -206,7 +206,7 @@ HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
             else if (r >= 3 && r < 6 && c >= 12 && (c - 12) % 3 == r - 3) q -= dt * P.contact[(c - 12) / 3] * P.w_foot_reg[r - 3];
             else if (c >= 3 && c < 6 && r >= 12 && (r - 12) % 3 == c - 3) q -= dt * P.contact[(r - 12) / 3] * P.w_foot_reg[c - 3];
         }
-        P.lxx[kk * P.rs + e] = q;
+        rec_put(P, kk, P.oLxx + e, q);
         // luu: tracking diagonal + GRF barrier 3x3 block of a stance foot (rows [0 0 1; -1 0 mu; 1 0 mu; 0 -1 mu; 0 1 mu])
         double uu = (r == c) ? dt * P.r[r] : 0.0;
         if (P.go_grf >= 0 && r < 12 && c < 12 && r / 3 == c / 3) {
@@ -217,7 +217,7 @@ HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
                 uu += dt * L.bdd[P.go_grf + 5 * a2 + cc] * vr * vc;
             }
         }
-        P.luu[kk * P.rs + e] = uu;
+        rec_put(P, kk, P.oLuu + e, uu);
     } if (tid < 24) {
         const int i = tid;
         double lx = dt * P.q[i] * (L.x[i] - P.xr[(size_t)k * 24 + i]);
@@ -226,7 +226,7 @@ HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
             if (i >= 3 && i < 6) { for (int f = 0; f < 4; f++) lx -= dt * P.contact[f] * P.w_foot_reg[i - 3] * ((L.x[12 + 3 * f + i - 3] - L.x[i]) - (fp[3 * f + i - 3] - bp[i - 3])); }
             else if (i >= 12) { const int f = (i - 12) / 3, a = (i - 12) % 3; lx += dt * P.contact[f] * P.w_foot_reg[a] * ((L.x[i] - L.x[3 + a]) - (fp[3 * f + a] - bp[a])); }
         }
-        P.lx[kk * P.rs + i] = lx;
+        rec_put(P, kk, P.oLx + i, lx);
         double lu = dt * P.r[i] * (L.u[i] - P.ur[(size_t)k * 24 + i]);
         if (P.go_grf >= 0 && i < 12) {
             const int f = i / 3; int a2 = -1; for (int t = 0; t < P.nc; t++) if (P.feet[t] == f) a2 = t;
@@ -235,7 +235,7 @@ HD void hkd_lq_knot(HkdLds& L, PhaseC& P, int b, int k, int reb_active) {
                 lu += dt * L.bd[P.go_grf + 5 * a2 + cc] * ((i % 3 == 0) ? r0 : (i % 3 == 1) ? r1 : r2);
             }
         }
-        P.lu[kk * P.rs + i] = lu;
+        rec_put(P, kk, P.oLu + i, lu);
     })
 }
 

@@ -111,6 +111,9 @@ HD double hs_rsqrt(double x) { return rsqrt(x); }
 #endif
 
 #ifndef HS_HOST_EMU
+HD double hs_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+HD float hs_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+HD float hs_readlane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 // broadcast of lane `src` (compile-time constant after unrolling -> v_readlane_b32 x2 into an SGPR pair)
 HD double hs_readlane(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);

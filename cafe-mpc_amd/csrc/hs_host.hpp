@@ -20,7 +20,7 @@ inline bool phase_chain_ok(int model, int next_model) {
 // Mem policy: void* alloc(size_t bytes) (zero-filled, nullptr on failure); void upload(void* dst, const void* src, size_t bytes);
 //             void replicate(void* base, size_t bytes_one, size_t count): copies record 0 into records 1..count-1
 template <class Mem>
-int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t* next, bool is_last, size_t B, PhaseDev& P, int slot0) {
+int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t* next, bool is_last, size_t B, PhaseDev& P, int slot0, bool f32 = false) {
     std::memset(&P, 0, sizeof(P));
     P.model = d.model; P.h = d.horizon; P.dt = d.dt; P.bg_alpha = d.BG_alpha;
     if (d.model == HSDDP_MODEL_WB) { P.n = 36; P.m = 12; P.p = 12; } else if (d.model == HSDDP_MODEL_SRB) { P.n = 12; P.m = 12; P.p = 0; } else { P.n = 24; P.m = 24; P.p = 0; }
@@ -72,7 +72,10 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
         auto rnd = [](size_t x) { return (x + 255) / 256 * 256; };
         const size_t oA = 0, oLxx = oA + rnd(n * n), oB = oLxx + rnd(n * n), oC = oB + rnd(n * m), oD = oC + rnd(py * n), oLuu = oD + rnd(py * m),
                      oLyy = oLuu + rnd(m * m), oLx = oLyy + rnd(py * py), oLu = oLx + n, oLy = oLu + m, size = oLx + rnd(n + m + py);
-        P.rs = (int)size; al(&P.rec, B * hh * size);
+        P.rs = (int)size;
+        P.oA = (int)oA; P.oLxx = (int)oLxx; P.oB = (int)oB; P.oC = (int)oC; P.oD = (int)oD; P.oLuu = (int)oLuu; P.oLyy = (int)oLyy; P.oLx = (int)oLx; P.oLu = (int)oLu; P.oLy = (int)oLy;
+        if (f32) { void* p = mem.alloc(std::max<size_t>(B * hh * size, 1) * sizeof(float)); if (!p) ok = false; P.rec32 = (float*)p; }
+        else al(&P.rec, B * hh * size);
         if (P.rec) { P.A = P.rec + oA; P.lxx = P.rec + oLxx; P.B = P.rec + oB; P.C = P.rec + oC; P.D = P.rec + oD; P.luu = P.rec + oLuu;
                      P.lyy = P.rec + oLyy; P.lx = P.rec + oLx; P.lu = P.rec + oLu; P.ly = P.rec + oLy; }
     }

@@ -6,66 +6,86 @@
 namespace hs {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+// accumulator type and lane -> row map of the 16x16x4 matrix-core instruction per scalar type.  Lane l = (li = l & 15, lk = l >> 4) feeds
+// A[i = li][k = lk], B[k = lk][j = li] in both; it owns column li of C and the rows  lk + 4 r  (v_mfma_f64_16x16x4_f64)  /  4 lk + r
+// (v_mfma_f32_16x16x4_f32), r = 0..3  (tools/mfma_layout_test.hip prints both maps from the hardware).
+template <class R> struct MfmaT;
+template <> struct MfmaT<double> {
+    using acc = d4_t;
+    static HD int row(int lk, int r) { return lk + 4 * r; }
+#ifndef HS_HOST_EMU
+    static HD acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+#endif
+};
+template <> struct MfmaT<float> {
+    using acc = f4_t;
+    static HD int row(int lk, int r) { return 4 * lk + r; }
+#ifndef HS_HOST_EMU
+    static HD acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
+};
 
 // Several 16x16 output tiles of ONE wave, accumulated together: the k-loop is outermost so that the MFMAs issued back to
 // back belong to different accumulators (a tile's own MFMAs form a dependent chain) and all operand loads of a k-step are in
 // flight together.  A tile may chain a second product onto the same accumulator (A^T HA + C^T lC).
-struct MTile {
-    double* Cout; int ldc; const double* Cin; int ldcin; int i0, j0, M_, N_;
-    const double* A; int lda; const double* B; int ldb; int K; bool TA;     // A(i,k) = TA ? A[k + lda*i] : A[i + lda*k] ; B(k,j) = TB ? B[j + ldb*k] : B[k + ldb*j] ; k >= K reads as 0
-    const double* A2; int lda2; const double* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
+template <class R = double> struct MTileT {
+    R* Cout; int ldc; const R* Cin; int ldcin; int i0, j0, M_, N_;
+    const R* A; int lda; const R* B; int ldb; int K; bool TA;     // A(i,k) = TA ? A[k + lda*i] : A[i + lda*k] ; B(k,j) = TB ? B[j + ldb*k] : B[k + ldb*j] ; k >= K reads as 0
+    const R* A2; int lda2; const R* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
     bool TB = false;
     bool TC = false;      // C(i,j) (and Cin) at C[j + ldc*i] instead of C[i + ldc*j]
-    double dadd = 0.0;    // added to the entries C(i,i) of the tile's block (i.e. where the absolute row equals the absolute column)
+    R dadd = 0.0;    // added to the entries C(i,i) of the tile's block (i.e. where the absolute row equals the absolute column)
 };
-template <int NTL, int KMAX, int KMAX2>
-HD void mfma_tiles(int lane, const MTile* td) {
+using MTile = MTileT<double>;
+template <int NTL, int KMAX, int KMAX2, class R>
+HD void mfma_tiles(int lane, const MTileT<R>* td) {
 #ifdef HS_HOST_EMU
     if (lane != 0) return;     // the emulator lets lane 0 stand for the wave (plain loops); the lane mapping is verified on the GPU
-    static double res[NTL][256];   // every tile is formed before any is stored, like the GPU path (in-place products)
+    static R res[NTL][256];   // every tile is formed before any is stored, like the GPU path (in-place products)
     for (int t = 0; t < NTL; t++) {
-        const MTile& T = td[t];
+        const MTileT<R>& T = td[t];
         for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
-            double s = T.Cin ? (T.TC ? T.Cin[j + T.ldcin * i] : T.Cin[i + T.ldcin * j]) : 0.0;
+            R s = T.Cin ? (T.TC ? T.Cin[j + T.ldcin * i] : T.Cin[i + T.ldcin * j]) : 0.0;
             for (int k = 0; k < T.K; k++) s += (T.TA ? T.A[k + T.lda * i] : T.A[i + T.lda * k]) * (T.TB ? T.B[j + T.ldb * k] : T.B[k + T.ldb * j]);
             for (int k = 0; k < T.K2; k++) s += T.A2[k + T.lda2 * i] * T.B2[k + T.ldb2 * j];
             res[t][(i - T.i0) + 16 * (j - T.j0)] = s;
         }
     }
     for (int t = 0; t < NTL; t++) {
-        const MTile& T = td[t];
+        const MTileT<R>& T = td[t];
         for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
-            const double v = res[t][(i - T.i0) + 16 * (j - T.j0)] + ((i == j) ? T.dadd : 0.0);
+            const R v = res[t][(i - T.i0) + 16 * (j - T.j0)] + ((i == j) ? T.dadd : 0.0);
             if (T.TC) T.Cout[j + T.ldc * i] = v; else T.Cout[i + T.ldc * j] = v;
         }
     }
 #else
     const int li = lane & 15, lk = lane >> 4;
-    d4_t c[NTL];
+    typename MfmaT<R>::acc c[NTL];
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
         const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0; }
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0; }
     }
     _Pragma("unroll") for (int kg = 0; kg < KMAX / 4; kg++) {
         _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K) {
             const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
             const bool kv = k < td[t].K;
-            const double a = (i < td[t].M_ && kv) ? (td[t].TA ? td[t].A[k + td[t].lda * i] : td[t].A[i + td[t].lda * k]) : 0.0;
-            const double b = (j < td[t].N_ && kv) ? (td[t].TB ? td[t].B[j + td[t].ldb * k] : td[t].B[k + td[t].ldb * j]) : 0.0;
-            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
+            const R a = (i < td[t].M_ && kv) ? (td[t].TA ? td[t].A[k + td[t].lda * i] : td[t].A[i + td[t].lda * k]) : 0.0;
+            const R b = (j < td[t].N_ && kv) ? (td[t].TB ? td[t].B[j + td[t].ldb * k] : td[t].B[k + td[t].ldb * j]) : 0.0;
+            c[t] = MfmaT<R>::mma(a, b, c[t]);
         }
     }
     _Pragma("unroll") for (int kg = 0; kg < KMAX2 / 4; kg++) {
         _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K2) {
             const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
-            const double a = (i < td[t].M_) ? td[t].A2[k + td[t].lda2 * i] : 0.0;
-            const double b = (j < td[t].N_) ? td[t].B2[k + td[t].ldb2 * j] : 0.0;
-            c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[t], 0, 0, 0);
+            const R a = (i < td[t].M_) ? td[t].A2[k + td[t].lda2 * i] : 0.0;
+            const R b = (j < td[t].N_) ? td[t].B2[k + td[t].ldb2 * j] : 0.0;
+            c[t] = MfmaT<R>::mma(a, b, c[t]);
         }
     }
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
         const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + lk + 4 * r; if (row < td[t].M_ && j < td[t].N_) { const double v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
     }
 #endif
 }

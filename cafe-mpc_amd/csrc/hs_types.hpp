@@ -51,12 +51,21 @@ struct PhaseDev {
     // lx lu ly, each sub-array starting at a multiple of 256 doubles (REC_* offsets), so that the Riccati workgroup
     // streams a knot with one base pointer and unit stride.  A, lxx, ... below point INTO rec: element e of knot kk is P.A[kk*rs + e].
     HS_GLOBAL double* rec; int rs;
+    // fp32 handles (hsddp_create_ex, HSDDP_PREC_F32): the record holds floats (same element offsets), rec is null and the A ... ly pointers
+    // below are unset; knot programs store through rec_put, the sweep reads rec32
+    HS_GLOBAL float* rec32;
+    int oA, oLxx, oB, oC, oD, oLuu, oLyy, oLx, oLu, oLy;                         // element offsets of the sub-arrays inside a knot's record
     HS_GLOBAL double *l, *lbase, *lx, *lu, *ly, *lxx, *luu, *lyy;                // running cost data (lux == 0 for every shipped cost)
     HS_GLOBAL double *Phi, *Phibase, *Phix, *Phixx, *H0, *Px;                    // per problem: 1, 1, n, n*n, n*n, next_n*n
     HS_GLOBAL double *g, *delta, *eps;                                           // h x ng
     HS_GLOBAL double* kc;                                                        // whole-body phases: contact-solve cache of the last rollout, h x KC_SIZE
     HS_GLOBAL double *th, *sigma, *lambda;                                       // nt
 };
+
+// store into the LQ record of knot kk in the precision the handle keeps it in
+template <class PD> HD void rec_put(PD& P, size_t kk, int off, double v) {
+    if (P.rec32 != nullptr) P.rec32[kk * P.rs + off] = (float)v; else P.rec[kk * P.rs + off] = v;
+}
 
 // how device code sees a descriptor: constant memory (scalar loads, values survive memory clobbers)
 using PhaseC = const HS_CONST PhaseDev;

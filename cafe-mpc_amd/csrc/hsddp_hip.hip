@@ -233,19 +233,16 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slo
     }
 }
 
-__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
-                                                int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
-    const PhaseDev* ph = ph_;   // (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there)
+template <class R>
+__device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, const OptDev& opt, ProbState* st, double fixed_reg, int regularized,
+                                           int do_linear, double lin_eps, int* success_out) {
     const int b = blockIdx.x;
-    if (masked_out(st[b], mask)) return;
-    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
-    __shared__ SweepLds S;
     bool success = false;
     if (regularized) {   // MultiPhaseDDP::backward_sweep_regularized (MultiPhaseDDP.cpp:136-165)
         double reg = st[b].reg; int iter = 0;
         while (true) {
             iter++;
-            success = riccati_sweep<SW_NT>(S, ph, nph, b, reg);
+            success = riccati_sweep<SW_NT, R>(S, ph, nph, b, (R)reg);
             if (success) break;
             reg = fmax(reg * opt.update_regularization, 1e-3);
             if (reg > 1e2) break;
@@ -253,18 +250,43 @@ __global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, i
         reg = reg / 20; if (reg < 1e-6) reg = 0;
         if (threadIdx.x == 0) { st[b].reg = reg; st[b].reg_total += iter; st[b].bs_ok = success ? 1 : 0; }
     } else {
-        success = riccati_sweep<SW_NT>(S, ph, nph, b, fixed_reg);
+        success = riccati_sweep<SW_NT, R>(S, ph, nph, b, (R)fixed_reg);
         if (threadIdx.x == 0 && success_out) success_out[b] = success ? 1 : 0;
     }
-    if (success && do_linear) linear_rollout<SW_NT>(S, ph, nph, b, lin_eps);
+    if (success && do_linear) linear_rollout<SW_NT, R>(S, ph, nph, b, (R)lin_eps);
     __syncthreads();
     if (threadIdx.x == 0) { st[b].dV_1 = S.c.dV1; st[b].dV_2 = S.c.dV2; }
+}
+__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
+                                                int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
+    const PhaseDev* ph = ph_;   // (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there)
+    if (masked_out(st[blockIdx.x], mask)) return;
+    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
+    __shared__ SweepLds S;
+    sweep_body<double>(S, ph, nph, opt, st, fixed_reg, regularized, do_linear, lin_eps, success_out);
+}
+// fp32 handles (hsddp_create_ex): fp32 LQ records, every product of the Riccati step on v_mfma_f32_16x16x4_f32, an LDS block a third the size
+// (kinodynamic 24/24/0 and single-rigid-body phases only: SinglePhase.cpp:565-567, HKDModel.h:33-61)
+__global__ void __launch_bounds__(SW_NT, 4) k_sweep32(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
+                                                     int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
+    const PhaseDev* ph = ph_;
+    if (masked_out(st[blockIdx.x], mask)) return;
+    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
+    __shared__ SweepLds32 S;
+    sweep_body<float>(S, ph, nph, opt, st, fixed_reg, regularized, do_linear, lin_eps, success_out);
 }
 
 __global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
     const PhaseDev* ph = ph_;
     __shared__ SweepLds S;
-    linear_rollout<SW_NT>(S, ph, nph, blockIdx.x, eps);
+    linear_rollout<SW_NT, double>(S, ph, nph, blockIdx.x, eps);
+    __syncthreads();
+    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
+}
+__global__ void __launch_bounds__(SW_NT, 4) k_linear32(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
+    const PhaseDev* ph = ph_;
+    __shared__ SweepLds32 S;
+    linear_rollout<SW_NT, float>(S, ph, nph, blockIdx.x, (float)eps);
     __syncthreads();
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
 }
@@ -469,6 +491,7 @@ struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 
 struct hsddp_handle {
     int nph = 0, batch = 0, device = 0, nslots = 0;
+    bool f32 = false;                 // HSDDP_PREC_F32: fp32 LQ records + fp32 Riccati sweep / linear rollout (kinodynamic and SRB phases)
     std::vector<PhaseDev> ph;         // host copy (device pointers inside)
     PhaseDev* d_ph = nullptr;
     PhaseDev* d_ph_ss = nullptr;      // the same descriptors with every shooting flag cleared: what option.MS = false rolls out (MultiPhaseDDP.cpp:65-68)
@@ -580,9 +603,10 @@ struct HipMem {
     void replicate(void* base, size_t one, size_t count) { hipError_t e = dev_replicate(base, one, count); if (e != hipSuccess) fail(e, "hipMemcpy D2D", one * count); }
 };
 
-int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
-    if (!out || n_phases <= 0 || !phases || batch <= 0) return HSDDP_EINVAL;
+int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device, int precision) {
+    if (!out || n_phases <= 0 || !phases || batch <= 0 || (precision != HSDDP_PREC_F64 && precision != HSDDP_PREC_F32)) return HSDDP_EINVAL;
     for (int i = 0; i < n_phases; i++) {
+        if (precision == HSDDP_PREC_F32 && phases[i].model == HSDDP_MODEL_WB) { fprintf(stderr, "[hsddp_hip] HSDDP_PREC_F32 covers kinodynamic (HKD) and single-rigid-body phases; whole-body phases need fp64\n"); return HSDDP_ENOTSUP; }
         if (phases[i].model != HSDDP_MODEL_WB && phases[i].model != HSDDP_MODEL_SRB && phases[i].model != HSDDP_MODEL_HKD) return HSDDP_EINVAL;
         if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) { fprintf(stderr, "[hsddp_hip] phase %d: the reference has no reset map from model %d to model %d (MHPCReset.cpp:4-52, HKDReset.h)\n", i, phases[i - 1].model, phases[i].model); return HSDDP_ENOTSUP; }
         if (!phases[i].shooting && i == 0) { fprintf(stderr, "[hsddp_hip] phase 0 must have shooting nodes (single shooting over the whole horizon is option.MS = 0)\n"); return HSDDP_ENOTSUP; }
@@ -591,7 +615,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) { fprintf(stderr, "[hsddp_hip] no HIP device %d\n", device); return HSDDP_ENODEV; }
     HIPCK(hipSetDevice(device));
     hsddp_handle* h = new hsddp_handle();
-    h->nph = n_phases; h->batch = batch; h->device = device;
+    h->nph = n_phases; h->batch = batch; h->device = device; h->f32 = precision == HSDDP_PREC_F32;
     // from here on every failure goes through hsddp_destroy(h): nothing allocated so far is leaked
 #define CREATE_CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); hsddp_destroy(h); return HSDDP_ENODEV; } } while (0)
     CREATE_CK(hipStreamCreate(&h->stream));
@@ -603,7 +627,7 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     int rc = 0;
     HipMem mem{h};
     for (int i = 0; i < n_phases && !rc; i++) {
-        rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, h->ph[i], (int)sp.size());
+        rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, h->ph[i], (int)sp.size(), h->f32);
         if (!rc && mem.err != hipSuccess) rc = (mem.err == hipErrorOutOfMemory) ? HSDDP_ENOMEM : HSDDP_ENODEV;
         for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
     }
@@ -627,6 +651,10 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
 #undef CREATE_CK
     *out = h; return HSDDP_OK;
 }
+int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device) {
+    return hsddp_create_ex(out, n_phases, phases, mp, batch, device, HSDDP_PREC_F64);
+}
+int hsddp_precision(hsddp_handle_t* h) { return (h && h->f32) ? HSDDP_PREC_F32 : HSDDP_PREC_F64; }
 
 // setup_phase memory policies of hsddp_reconfigure: (1) SizeMem walks the layout without touching memory, (2) ArenaMem lays the window out in
 // one arena by bumping a pointer; zero-fill, uploads and replications are queued and issued afterwards on the handle's stream
@@ -661,7 +689,9 @@ int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t*
         if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) return HSDDP_ENOTSUP;
         if ((!phases[i].shooting && i == 0) || phases[i].horizon <= 0 || shift[i] < 0 || src_phase[i] >= h->nph) return HSDDP_EINVAL;
         if (src_phase[i] >= 0 && h->ph[src_phase[i]].model != phases[i].model) return HSDDP_EINVAL;
+        if (h->f32 && phases[i].model == HSDDP_MODEL_WB) return HSDDP_ENOTSUP;
     }
+    if (phases[0].model != h->ph[0].model) return HSDDP_EINVAL;      // (the initial-condition buffer is sized for the first phase's model)
     HIPCK(hipSetDevice(h->device));
     const size_t B = h->batch;
     // 1. size of the new window, arena to build it in (grown only when the window outgrows it: the first ticks)
@@ -669,7 +699,7 @@ int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t*
     std::vector<int> sp, sk;
     {
         SizeMem sz;
-        for (int i = 0; i < n_phases; i++) { int rc = setup_phase(sz, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], 0); if (rc) return rc; }
+        for (int i = 0; i < n_phases; i++) { int rc = setup_phase(sz, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], 0, h->f32); if (rc) return rc; }
         const int g = (h->cur_arena == 0) ? 1 : 0;
         auto& A = h->arena[g];
         if (sz.used > A.cap) {
@@ -682,7 +712,7 @@ int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t*
         h->staged.clear();
         ArenaMem mem{h, &A};
         for (int i = 0; i < n_phases; i++) {
-            int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], (int)sp.size()); if (rc) return rc;
+            int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, B, np[i], (int)sp.size(), h->f32); if (rc) return rc;
             for (int k = 0; k <= phases[i].horizon; k++) { sp.push_back(i); sk.push_back(k); }
         }
         HIPCK(mem.flush());
@@ -775,7 +805,8 @@ static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
 }
 static void launch_sweep(hsddp_handle* h, const OptDev& o, int mask, double reg, int regularized, int do_linear, double lin_eps, int* succ) {
     Timed t(h, "k_sweep");
-    hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
+    if (h->f32) hipLaunchKernelGGL(k_sweep32, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
+    else hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
 }
 static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, bool count, int iter_ou) {
     Timed t(h, "k_eval");
@@ -903,7 +934,9 @@ int hsddp_backward_sweep(hsddp_handle_t* h, double regularization, int* success)
 }
 int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* opt) {
     (void)opt; if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device));
-    { Timed t(h, "k_linear"); hipLaunchKernelGGL(k_linear, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps); }
+    { Timed t(h, "k_linear");
+      if (h->f32) hipLaunchKernelGGL(k_linear32, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps);
+      else hipLaunchKernelGGL(k_linear, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps); }
     HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
 }
 int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {
@@ -954,6 +987,15 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     HIPCK(hipSetDevice(h->device));
     int count, elems, stride; const double* src = field_dev(h->ph[phase], field, count, elems, stride);
     const size_t sz = (size_t)count * elems;
+    if (h->f32 && stride != elems && sz > 0 && nb > 0) {      // a field inside the LQ record of an fp32 handle: floats on the device
+        const PhaseDev& P = h->ph[phase];
+        const int off = field == HSDDP_F_A ? P.oA : field == HSDDP_F_B ? P.oB : field == HSDDP_F_C ? P.oC : field == HSDDP_F_D ? P.oD : field == HSDDP_F_LX ? P.oLx : field == HSDDP_F_LU ? P.oLu :
+                        field == HSDDP_F_LY ? P.oLy : field == HSDDP_F_LXX ? P.oLxx : field == HSDDP_F_LUU ? P.oLuu : P.oLyy;
+        std::vector<float> tmp(sz * nb);
+        HIPCK(hipMemcpy2D(tmp.data(), (size_t)elems * 4, P.rec32 + (size_t)b0 * count * stride + off, (size_t)stride * 4, (size_t)elems * 4, (size_t)nb * count, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); i++) dst[i] = tmp[i];
+        return HSDDP_OK;
+    }
     if (!src) { memset(dst, 0, sz * nb * 8); return HSDDP_OK; }
     if (sz == 0 || nb == 0) return HSDDP_OK;
     if (stride == elems) HIPCK(hipMemcpy(dst, src + (size_t)b0 * sz, sz * nb * 8, hipMemcpyDeviceToHost));

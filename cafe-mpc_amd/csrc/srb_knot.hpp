@@ -139,14 +139,14 @@ HD void srb_lq_knot(SrbLds& L, PhaseC& P, int b, int k, int reb_active) {
     })
     HS_PHASE(NT, for (int e = tid; e < 144; e += NT) {
         const int r = e % 12, c = e / 12;
-        P.A[kk * P.rs + e] = L.AB[e]; P.B[kk * P.rs + e] = L.AB[144 + e];
+        rec_put(P, kk, P.oA + e, L.AB[e]); rec_put(P, kk, P.oB + e, L.AB[144 + e]);
         double qd = 0, rd = 0;
         if (r == c) { qd = dt * P.q[r]; rd = dt * P.r[r]; if (r == 2) qd += dt * L.bdd; }
-        P.lxx[kk * P.rs + e] = qd; P.luu[kk * P.rs + e] = rd;
+        rec_put(P, kk, P.oLxx + e, qd); rec_put(P, kk, P.oLuu + e, rd);
     } if (tid < 12) {
         double lx = dt * P.q[tid] * (L.x[tid] - P.xr[(size_t)k * 12 + tid]); if (tid == 2) lx += dt * L.bd;
-        P.lx[kk * P.rs + tid] = lx;
-        P.lu[kk * P.rs + tid] = dt * P.r[tid] * (L.u[tid] - P.ur[(size_t)k * 12 + tid]);
+        rec_put(P, kk, P.oLx + tid, lx);
+        rec_put(P, kk, P.oLu + tid, dt * P.r[tid] * (L.u[tid] - P.ur[(size_t)k * 12 + tid]));
     })
 }
 

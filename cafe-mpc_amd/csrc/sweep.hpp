@@ -21,6 +21,8 @@
 //  * the 12x12 (24x24) LDLT + inverse runs inside wave 0: rows in registers, pivots and multipliers by lane broadcast.
 #pragma once
 #include <cstddef>
+#include <limits>
+#include <type_traits>
 #include "hs_types.hpp"
 #include "hs_mfma.hpp"
 
@@ -43,15 +45,16 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 
 // LDS working set of one Riccati step for a model with dims (N, M, PY); leading dimensions padded to rows + 1
 // (conflict-free column access).  All three instantiations are views over the same raw LDS block (SweepLds).
-template <int N, int M, int PY> struct SweepLdsT {
+// R: the scalar the sweep computes in - double, or float for the fp32 handles of hsddp_create_ex (fp32 LQ records, v_mfma_f32_16x16x4_f32)
+template <int N, int M, int PY, class R = double> struct SweepLdsT {
     static constexpr int LDN = N + 1, LDM = (M > PY ? M : PY) + 1, PYd = PY > 0 ? PY : 1;
-    double H[LDN * N], A[LDN * N], HA[LDN * N], Qxx[LDN * N];
-    double B[LDN * M], HB[LDN * M];
-    double Qux[LDM * N], K[LDM * N], C[PY > 0 ? LDM * N : 1], lC[PY > 0 ? LDM * N : 1];
-    double D[PY > 0 ? LDM * M : 1], lD[PY > 0 ? LDM * M : 1], lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M], LQ[LDM * M];
-    double G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N], rdQ[M];
-    double dx[N], dxn[N], du[M];
-    double red[SW_NT];
+    R H[LDN * N], A[LDN * N], HA[LDN * N], Qxx[LDN * N];
+    R B[LDN * M], HB[LDN * M];
+    R Qux[LDM * N], K[LDM * N], C[PY > 0 ? LDM * N : 1], lC[PY > 0 ? LDM * N : 1];
+    R D[PY > 0 ? LDM * M : 1], lD[PY > 0 ? LDM * M : 1], lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M], LQ[LDM * M];
+    R G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N], rdQ[M];
+    R dx[N], dxn[N], du[M];
+    R red[SW_NT];
 };
 // what survives a phase boundary: value-function gradient / state deviation handed to the neighbouring phase, dV, status
 struct SweepCtl { double dV1, dV2, xfer[SW_N]; unsigned long long t_last; int ok; };
@@ -60,6 +63,12 @@ using SweepSRB = SweepLdsT<12, 12, 0>;
 using SweepHKD = SweepLdsT<24, 24, 0>;
 struct SweepLds { double raw[sizeof(SweepWB) / sizeof(double)]; SweepCtl c; };
 static_assert(sizeof(SweepHKD) <= sizeof(SweepWB) && sizeof(SweepSRB) <= sizeof(SweepWB), "the whole-body view is the largest");
+// the fp32 handles hold kinodynamic / single-rigid-body phases only: their LDS block is a third of the fp64 one (six workgroups per CU)
+using SweepHKD32 = SweepLdsT<24, 24, 0, float>;
+struct SweepLds32 { float raw[sizeof(SweepHKD32) / sizeof(float)]; SweepCtl c; };
+static_assert(sizeof(SweepLdsT<12, 12, 0, float>) <= sizeof(SweepHKD32), "the kinodynamic view is the largest fp32 one");
+template <class R> struct SweepLdsOf { using type = SweepLds; };
+template <> struct SweepLdsOf<float> { using type = SweepLds32; };
 
 #define CM(M, i, j, ld) (M)[(i) + (ld) * (j)]
 
@@ -75,10 +84,10 @@ __device__ unsigned long long g_sw_prof[16];
 
 // per-thread prefetch registers (the host lane emulator keeps one row per emulated thread)
 #ifdef HS_HOST_EMU
-#define SW_PRE_DECL static double pre_all_[SW_NT][SW_PRE];
+#define SW_PRE_DECL static R pre_all_[SW_NT][SW_PRE];
 #define PRE(r) pre_all_[tid][r]
 #else
-#define SW_PRE_DECL double pre_[SW_PRE];
+#define SW_PRE_DECL R pre_[SW_PRE];
 #define PRE(r) pre_[r]
 #endif
 
@@ -91,18 +100,20 @@ template <int CTRL> HD double dpp_quad(double v) {
     return __hiloint2double(hi, lo);
 }
 HD double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }     // quad_perm [1,0,3,2], then [2,3,0,1]
+template <int CTRL> HD float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+HD float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 #endif
 // SW_QUAD_ROWS(CNT, PARTIAL, FINISH): for each output o < CNT, PARTIAL computes `partial` and `partial2` from (o, part = 0..3), FINISH
 // consumes `total` / `total2` = (p0 + p1) + (p2 + p3).  GPU: the four lanes of quad o (tid = 4 o + part), FINISH on the part-0 lane;
 // emulator: thread o does all four parts itself.  SW_QS: lane stride between the lanes that run FINISH.
 #ifdef HS_HOST_EMU
 #define SW_QS 1
-#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if (tid < (CNT)) { const int o = tid; double p_[4]; double p2_[4]; for (int part = 0; part < 4; part++) { double partial = 0; double partial2 = 0; PARTIAL p_[part] = partial; p2_[part] = partial2; } \
-    const double total = (p_[0] + p_[1]) + (p_[2] + p_[3]); const double total2 = (p2_[0] + p2_[1]) + (p2_[2] + p2_[3]); (void)total2; FINISH }
+#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if (tid < (CNT)) { const int o = tid; R p_[4]; R p2_[4]; for (int part = 0; part < 4; part++) { R partial = 0; R partial2 = 0; PARTIAL p_[part] = partial; p2_[part] = partial2; } \
+    const R total = (p_[0] + p_[1]) + (p_[2] + p_[3]); const R total2 = (p2_[0] + p2_[1]) + (p2_[2] + p2_[3]); (void)total2; FINISH }
 #else
 #define SW_QS 4
-#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if ((tid >> 2) < (CNT)) { const int o = tid >> 2; const int part = tid & 3; double partial = 0; double partial2 = 0; PARTIAL \
-    const double total = quad_sum(partial); const double total2 = quad_sum(partial2); (void)total2; if (part == 0) FINISH }
+#define SW_QUAD_ROWS(CNT, PARTIAL, FINISH) if ((tid >> 2) < (CNT)) { const int o = tid >> 2; const int part = tid & 3; R partial = 0; R partial2 = 0; PARTIAL \
+    const R total = quad_sum(partial); const R total2 = quad_sum(partial2); (void)total2; if (part == 0) FINISH }
 #endif
 
 // ---- wave 0: Eigen's pivoted LDLT and the explicit inverse ------------------------------------------------------------------
@@ -120,40 +131,40 @@ HD double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); r
 // same sequence of multiply-adds as in Eigen's loops.  The multipliers go to LDS once, and lanes 0..M-1 each solve one column of
 // the identity.  Output: NI = -(A + diag_add I)^-1 (the sign the gains need), column-major with leading dimension LD.
 // Scratch: Lw >= M*M doubles, iw >= M ints.
-template <int M, int LD>
-HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw, int* iw, int* ok) {
-    constexpr double TOL = 1.0 / 1.7976931348623157e308;
+template <int M, int LD, class R>
+HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
+    const R TOL = R(1.0) / std::numeric_limits<R>::max();
 #ifdef HS_HOST_EMU
     HS_WPHASE(if (tid == 0) {      // the emulator has no lanes to broadcast between: Eigen's loops as they stand, with physical swaps
-        double m[M * M]; int tr[M]; int sign = 0; (void)Lw; (void)iw;
+        R m[M * M]; int tr[M]; int sign = 0; (void)Lw; (void)iw;
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) m[i + M * j] = A[i + LD * j] + (i == j ? diag_add : 0.0);
-        auto Mx = [&](int i, int j) -> double& { return m[i + M * j]; };
-        double temp[M];
+        auto Mx = [&](int i, int j) -> R& { return m[i + M * j]; };
+        R temp[M];
         for (int k = 0; k < M; k++) {
-            int big = k; double best = std::fabs(Mx(k, k));
+            int big = k; R best = std::fabs(Mx(k, k));
             for (int i = k + 1; i < M; i++) if (std::fabs(Mx(i, i)) > best) { best = std::fabs(Mx(i, i)); big = i; }
             tr[k] = big;
             if (k != big) {
-                for (int j = 0; j < k; j++) { const double t = Mx(k, j); Mx(k, j) = Mx(big, j); Mx(big, j) = t; }
-                for (int i = big + 1; i < M; i++) { const double t = Mx(i, k); Mx(i, k) = Mx(i, big); Mx(i, big) = t; }
-                { const double t = Mx(k, k); Mx(k, k) = Mx(big, big); Mx(big, big) = t; }
-                for (int i = k + 1; i < big; i++) { const double t = Mx(i, k); Mx(i, k) = Mx(big, i); Mx(big, i) = t; }
+                for (int j = 0; j < k; j++) { const R t = Mx(k, j); Mx(k, j) = Mx(big, j); Mx(big, j) = t; }
+                for (int i = big + 1; i < M; i++) { const R t = Mx(i, k); Mx(i, k) = Mx(i, big); Mx(i, big) = t; }
+                { const R t = Mx(k, k); Mx(k, k) = Mx(big, big); Mx(big, big) = t; }
+                for (int i = k + 1; i < big; i++) { const R t = Mx(i, k); Mx(i, k) = Mx(big, i); Mx(big, i) = t; }
             }
             for (int j = 0; j < k; j++) temp[j] = Mx(j, j) * Mx(k, j);
-            { double s = 0; for (int j = 0; j < k; j++) s += Mx(k, j) * temp[j]; Mx(k, k) -= s; }
-            for (int i = k + 1; i < M; i++) { double t = 0; for (int j = 0; j < k; j++) t += Mx(i, j) * temp[j]; Mx(i, k) -= t; }
-            const double akk = Mx(k, k); const bool valid = std::fabs(akk) > 0.0;
+            { R s = 0; for (int j = 0; j < k; j++) s += Mx(k, j) * temp[j]; Mx(k, k) -= s; }
+            for (int i = k + 1; i < M; i++) { R t = 0; for (int j = 0; j < k; j++) t += Mx(i, j) * temp[j]; Mx(i, k) -= t; }
+            const R akk = Mx(k, k); const bool valid = std::fabs(akk) > 0.0;
             if (valid) for (int i = k + 1; i < M; i++) Mx(i, k) /= akk;
             if (sign == 1) { if (akk < 0) sign = 2; } else if (sign == -1) { if (akk > 0) sign = 2; } else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
         }
         if (!(sign == 1 || sign == 0)) *ok = 0;
         for (int c = 0; c < M; c++) {
-            double x[M]; for (int i = 0; i < M; i++) x[i] = (i == c) ? 1.0 : 0.0;
-            for (int k = 0; k < M; k++) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
-            for (int i = 0; i < M; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= Mx(i, j) * x[j]; x[i] = s; }
-            for (int i = 0; i < M; i++) { const double d = Mx(i, i); x[i] = (std::fabs(d) > TOL) ? x[i] / d : 0.0; }
-            for (int i = M - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < M; j++) s -= Mx(j, i) * x[j]; x[i] = s; }
-            for (int k = M - 1; k >= 0; k--) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+            R x[M]; for (int i = 0; i < M; i++) x[i] = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < M; k++) if (tr[k] != k) { const R t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+            for (int i = 0; i < M; i++) { R s = x[i]; for (int j = 0; j < i; j++) s -= Mx(i, j) * x[j]; x[i] = s; }
+            for (int i = 0; i < M; i++) { const R d = Mx(i, i); x[i] = (std::fabs(d) > TOL) ? x[i] / d : 0.0; }
+            for (int i = M - 1; i >= 0; i--) { R s = x[i]; for (int j = i + 1; j < M; j++) s -= Mx(j, i) * x[j]; x[i] = s; }
+            for (int k = M - 1; k >= 0; k--) if (tr[k] != k) { const R t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
             for (int i = 0; i < M; i++) NI[i + LD * c] = -x[i];
         }
     })
@@ -162,19 +173,19 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
     HS_WPHASE({
         const bool act = tid < M; const int me = act ? tid : M - 1;       // idle lanes mirror the last row (all 64 lanes run the broadcasts)
         // ---- pivot order
-        double dg[M];
+        R dg[M];
         _Pragma("unroll") for (int j = 0; j < M; j++) dg[j] = fabs(A[j + LD * j] + diag_add);
-        const double mine = fabs(A[me + LD * me] + diag_add);
+        const R mine = fabs(A[me + LD * me] + diag_add);
         int rank = 0; bool tie = false;
         _Pragma("unroll") for (int j = 0; j < M; j++) { const bool eq = (dg[j] == mine) && (j != me); rank += (dg[j] > mine || (eq && j < me)) ? 1 : 0; tie = tie || eq; }
         if (__builtin_amdgcn_ballot_w64(tie && act) == 0ull) { if (act) iw[rank] = me; }
         else {      // exact ties: Eigen's selection with swaps, literally, on wave-uniform registers
-            double v[M]; int ix[M];
+            R v[M]; int ix[M];
             _Pragma("unroll") for (int j = 0; j < M; j++) { v[j] = dg[j]; ix[j] = j; }
             _Pragma("unroll") for (int k = 0; k < M; k++) {
-                int big = k; double best = v[k];
+                int big = k; R best = v[k];
                 _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool bgr = v[i] > best; best = bgr ? v[i] : best; big = bgr ? i : big; }
-                const double vk = v[k]; const int ik = ix[k]; int ib = ik;
+                const R vk = v[k]; const int ik = ix[k]; int ib = ik;
                 _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool hit = (i == big); ib = hit ? ix[i] : ib; v[i] = hit ? vk : v[i]; ix[i] = hit ? ik : ix[i]; }
                 v[k] = best; ix[k] = ib;
                 if (tid == 0) iw[k] = ib;
@@ -185,7 +196,7 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
         _Pragma("unroll") for (int k = 0; k < M; k++) { pv[k] = iw[k]; myrank = (pv[k] == me) ? k : myrank; }
         const int prow = iw[me];
         // ---- row `me` of the permuted matrix (lower triangle of the input only)
-        double arow[M];
+        R arow[M];
         _Pragma("unroll") for (int j = 0; j < M; j++) { const int r = prow > pv[j] ? prow : pv[j], c = prow > pv[j] ? pv[j] : prow; arow[j] = A[r + LD * c] + ((j == me) ? diag_add : 0.0); }
         // ---- LDL^T of the permuted matrix, right-looking with the row in registers (the structure of chol_r): at step j every lane holds
         //      its column-j entry w = D_j L(me,j) of the current Schur complement in a[j]; the pivot D_j = w of lane j and the entries of
@@ -194,11 +205,11 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
         //      by the pivot as multiplications by its reciprocal.  Multipliers and reciprocal pivots go straight to LDS (row me of Lw).
         bool anyneg = false;
         _Pragma("unroll") for (int j = 0; j < M; j++) {
-            const double d = hs_readlane(arow[j], j);
-            double rd = __builtin_amdgcn_rcp(d); rd = rd * (2.0 - d * rd); rd = rd * (2.0 - d * rd);     // 1/d to the last bit or two (the IEEE division sequence is five times as long and sits on the chain from pivot to pivot)
+            const R d = hs_readlane(arow[j], j);
+            R rd = hs_rcp(d); rd = rd * (R(2.0) - d * rd); rd = rd * (R(2.0) - d * rd);     // 1/d to the last bit or two (the IEEE division sequence is five times as long and sits on the chain from pivot to pivot)
             rd = (fabs(d) > TOL) ? rd : 0.0;
             anyneg = anyneg || (d < 0.0);
-            const double lij = (fabs(d) > 0.0) ? arow[j] * rd : arow[j];
+            const R lij = (fabs(d) > 0.0) ? arow[j] * rd : arow[j];
             if (act) { if (me > j) Lw[me * M + j] = lij; else if (me == j) Lw[j * M + j] = rd; }
             _Pragma("unroll") for (int k = j + 1; k < M; k++) arow[k] -= lij * hs_readlane(arow[j], k);
         }
@@ -207,13 +218,13 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
         //      (broadcast reads) while the current row's multiply-add chain runs: a single wave has nothing else to hide the LDS latency behind.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         constexpr int NB = SW_LDLT_NB;      // (the 24-row factor of the kinodynamic model leaves no registers for a second row buffer)
-        double y[M], lr[NB][M];
+        R y[M], lr[NB][M];
         if (NB == 1) { lr[0][0] = 0.0; }
         _Pragma("unroll") for (int k = 0; k < M; k++) {
             if (NB == 2) { if (k + 1 < M) { _Pragma("unroll") for (int j = 0; j <= k; j++) lr[(k + 1) % NB][j] = Lw[(k + 1) * M + j]; } }
             else { _Pragma("unroll") for (int j = 0; j < k; j++) lr[0][j] = Lw[k * M + j]; }
             HS_CBAR();
-            double sacc = (k == myrank) ? 1.0 : 0.0;
+            R sacc = (k == myrank) ? 1.0 : 0.0;
             _Pragma("unroll") for (int j = 0; j < k; j++) sacc -= lr[k % NB][j] * y[j];
             HS_PIN(sacc);       // (the row's chain is evaluated HERE: otherwise every row's loads are issued first and their values spill)
             y[k] = sacc;
@@ -223,7 +234,7 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
             if (NB == 2) { if (k > 0) { _Pragma("unroll") for (int j = k; j < M; j++) lr[(k - 1) % NB][j] = Lw[j * M + (k - 1)]; } }
             else { _Pragma("unroll") for (int j = k + 1; j < M; j++) lr[0][j] = Lw[j * M + k]; }
             HS_CBAR();
-            double sacc = y[k];
+            R sacc = y[k];
             _Pragma("unroll") for (int j = k + 1; j < M; j++) sacc -= lr[k % NB][j] * y[j];
             HS_PIN(sacc);
             y[k] = sacc;
@@ -233,11 +244,11 @@ HD void ldlt_inverse_w(const double* A, double diag_add, double* NI, double* Lw,
 #endif
 }
 // global (dense, ld = rows) <-> LDS (padded ld); threads stride over columns with a fixed row
-template <int NT> HD void ld_mat(int tid, double* dst, int ldd, const double* src, int rows, int cols) {
+template <int NT, class TD, class TS> HD void ld_mat(int tid, TD* dst, int ldd, const TS* src, int rows, int cols) {
     const int i = tid % rows, j0 = tid / rows, js = NT / rows;
     if (j0 < js) for (int j = j0; j < cols; j += js) dst[i + ldd * j] = src[i + rows * j];
 }
-template <int NT> HD void st_mat(int tid, double* dst, const double* src, int lds_, int rows, int cols) {
+template <int NT, class TD, class TS> HD void st_mat(int tid, TD* dst, const TS* src, int lds_, int rows, int cols) {
     const int i = tid % rows, j0 = tid / rows, js = NT / rows;
     if (j0 < js) for (int j = j0; j < cols; j += js) dst[i + rows * j] = src[i + lds_ * j];
 }
@@ -245,9 +256,9 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
 // ---- prefetch of one knot's record (backward sweep): RL::rounds rounds of 256 elements, each inside ONE sub-array,
 //      plus one round for the vectors [lx(N) lu(M) ly(PY) Defect[k+1](N)]
 #define SW_RICCATI_FETCH(kk_, k_) { \
-    const double* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
+    const HS_GLOBAL R* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
     _Pragma("unroll") for (int r = 0; r < RL::rounds; r++) PRE(r) = rec_[NT * r];     /* one base pointer, constant offsets */ \
-    PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : 0.0; }
+    PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : R(0.0); }
 #define SW_RICCATI_COMMIT() { \
     constexpr int PYd = PY > 0 ? PY : 1; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } } \
@@ -259,80 +270,85 @@ template <int NT> HD void st_mat(int tid, double* dst, const double* src, int ld
     if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
     else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
 
+// the LQ records of a phase in the precision the sweep computes in
+template <class R> HD const HS_GLOBAL R* rec_of(const PhaseDev& P);
+template <> HD const HS_GLOBAL double* rec_of<double>(const PhaseDev& P) { return P.rec; }
+template <> HD const HS_GLOBAL float* rec_of<float>(const PhaseDev& P) { return P.rec32; }
+
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
-template <int W, int N, int M, int PY>
-HD void sweep_tiles1(SweepLdsT<N, M, PY>& S, int lane) {
-    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
+template <int W, int N, int M, int PY, class R>
+HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane) {
+    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16, TPd = TP > 0 ? TP : 1;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
     constexpr int NTL = (t4 - W + 3) / 4;
     if (NTL <= 0) return;
-    MTile td[NTL > 0 ? NTL : 1];
+    MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        if (t < t1) td[q] = MTile{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN, N, false, nullptr, 0, nullptr, 0, 0};
-        else if (t < t2) td[q] = MTile{S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN, N, false, nullptr, 0, nullptr, 0, 0};
-        else if (t < t3) td[q] = MTile{S.lC, LDM, nullptr, 0, 16 * ((t - t2) % TPd), 16 * ((t - t2) / TPd), PY, N, S.lyy, LDM, S.C, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
-        else td[q] = MTile{S.lD, LDM, nullptr, 0, 16 * ((t - t3) % TPd), 16 * ((t - t3) / TPd), PY, M, S.lyy, LDM, S.D, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
+        if (t < t1) td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN, N, false, nullptr, 0, nullptr, 0, 0};
+        else if (t < t2) td[q] = MTileT<R>{S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN, N, false, nullptr, 0, nullptr, 0, 0};
+        else if (t < t3) td[q] = MTileT<R>{S.lC, LDM, nullptr, 0, 16 * ((t - t2) % TPd), 16 * ((t - t2) / TPd), PY, N, S.lyy, LDM, S.C, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
+        else td[q] = MTileT<R>{S.lD, LDM, nullptr, 0, 16 * ((t - t3) % TPd), 16 * ((t - t3) / TPd), PY, M, S.lyy, LDM, S.D, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, 0>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, 0, R>(lane, td);
 }
-template <int W, int N, int M, int PY>
-HD void sweep_tiles2(SweepLdsT<N, M, PY>& S, int lane, double reg) {
-    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
+template <int W, int N, int M, int PY, class R>
+HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg) {
+    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
     // body), the symmetrisation step of the reference (SinglePhase.cpp:376) fills the rest
     constexpr int t1 = TN * (TN + 1) / 2, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
     constexpr int NTL = (t3 - W + 3) / 4;
     if (NTL <= 0) return;
-    MTile td[NTL > 0 ? NTL : 1];
+    MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
-        if (t < t1) { td[q] = MTile{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg; }     // regularisation on Qxx as well: quirk x
-        else if (t < t2) td[q] = MTile{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
-        else { td[q] = MTile{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
+        if (t < t1) { td[q] = MTileT<R>{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg; }     // regularisation on Qxx as well: quirk x
+        else if (t < t2) td[q] = MTileT<R>{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
+        else { td[q] = MTileT<R>{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4, R>(lane, td);
 }
 
 // H = Qxx + Qux^T K : the TN x TN tiles dealt round-robin, a wave's tiles interleaved (their short accumulation chains overlap)
-template <int W, int N, int M, int PY>
-HD void sweep_tiles3(SweepLdsT<N, M, PY>& S, int lane) {
-    constexpr int LDN = SweepLdsT<N, M, PY>::LDN, LDM = SweepLdsT<N, M, PY>::LDM;
+template <int W, int N, int M, int PY, class R>
+HD void sweep_tiles3(SweepLdsT<N, M, PY, R>& S, int lane) {
+    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM;
     constexpr int TN = (N + 15) / 16;
     constexpr int NTL = (TN * TN - W + 3) / 4;
     if (NTL <= 0) return;
-    MTile td[NTL > 0 ? NTL : 1];
+    MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        td[q] = MTile{S.H, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};
+        td[q] = MTileT<R>{S.H, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0, R>(lane, td);
 }
 
 // K = (-Quu_inv) Qux : TM x TN tiles dealt round-robin
-template <int W, int N, int M, int PY>
-HD void sweep_tilesK(SweepLdsT<N, M, PY>& S, int lane) {
-    constexpr int LDM = SweepLdsT<N, M, PY>::LDM;
+template <int W, int N, int M, int PY, class R>
+HD void sweep_tilesK(SweepLdsT<N, M, PY, R>& S, int lane) {
+    constexpr int LDM = SweepLdsT<N, M, PY, R>::LDM;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     constexpr int NTL = (TM * TN - W + 3) / 4;
     if (NTL <= 0) return;
-    MTile td[NTL > 0 ? NTL : 1];
+    MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        td[q] = MTile{S.K, LDM, nullptr, 0, 16 * (t % TM), 16 * (t / TM), M, N, S.LQ, LDM, S.Qux, LDM, M, false, nullptr, 0, nullptr, 0, 0};
+        td[q] = MTileT<R>{S.K, LDM, nullptr, 0, 16 * (t % TM), 16 * (t / TM), M, N, S.LQ, LDM, S.Qux, LDM, M, false, nullptr, 0, nullptr, 0, 0};
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0, R>(lane, td);
 }
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
-template <int NT, int N, int M, int PY>
-HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
-    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
+template <int NT, int N, int M, int PY, class R>
+HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R reg) {
+    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
     constexpr int LDN = ST::LDN, LDM = ST::LDM;
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
@@ -340,12 +356,12 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
     const int h = P.h;
     // trajectory pointers of the phase, read ONCE: a descriptor field fetched inside the knot loop is a vector load whose wait
     // (vmcnt(0)) would also drain the record prefetch that is meant to stay in flight for a whole knot
-    const auto grec = P.rec; const auto gDefect = P.Defect; const auto gQu = P.Qu; const auto gQuu = P.Quu; const auto gQux = P.Qux;
+    const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gQu = P.Qu; const auto gQuu = P.Quu; const auto gQux = P.Qux;
     const auto gK = P.K; const auto gdU = P.dU; const auto gG = P.G;
     SW_PRE_DECL
     // terminal: G[h] = Phix + Gprime ; H[h] = Phixx + Hprime  (SinglePhase.cpp:326-327); prefetch knot h-1
     HS_PHASE(NT, { const int i = tid % N, j0 = tid / N; if (j0 < NT / N) for (int j = j0; j < N; j += NT / N) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * N * N + i + N * j]; }
-             if (tid < N) { const double g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; gG[((size_t)b * (h + 1) + h) * N + tid] = g; }
+             if (tid < N) { const R g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; gG[((size_t)b * (h + 1) + h) * N + tid] = g; }
              if (tid == 0) { SWC.ok = 1; }
              SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1))
     for (int k = h - 1; k >= 0; k--) {
@@ -357,25 +373,25 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles1<0, N, M, PY>(S, lane); break; case 1: sweep_tiles1<1, N, M, PY>(S, lane); break;
-                         case 2: sweep_tiles1<2, N, M, PY>(S, lane); break; default: sweep_tiles1<3, N, M, PY>(S, lane); }
-            if (tid < N) { double s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
+            switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane); break;
+                         case 2: sweep_tiles1<2, N, M, PY, R>(S, lane); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane); }
+            if (tid < N) { R s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
         })
         SW_STAMP(1)
         // phase 2: Qxx += A^T HA + C^T lC (TN x TN) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles2<0, N, M, PY>(S, lane, reg); break; case 1: sweep_tiles2<1, N, M, PY>(S, lane, reg); break;
-                         case 2: sweep_tiles2<2, N, M, PY>(S, lane, reg); break; default: sweep_tiles2<3, N, M, PY>(S, lane, reg); }
+            switch (w) { case 0: sweep_tiles2<0, N, M, PY, R>(S, lane, reg); break; case 1: sweep_tiles2<1, N, M, PY, R>(S, lane, reg); break;
+                         case 2: sweep_tiles2<2, N, M, PY, R>(S, lane, reg); break; default: sweep_tiles2<3, N, M, PY, R>(S, lane, reg); }
             // the two mat-vec chains ride on waves 2 and 3, which carry two tiles each in this phase (waves 0 and 1: three)
             if (tid >= 128 && tid < 128 + N) {
-                const int i = tid - 128; double s = 0;
+                const int i = tid - 128; R s = 0;
                 _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
                 S.Qx[i] += s;
             } else if (tid >= 192 && tid < 192 + M) {
-                const int a = tid - 192; double s = 0;
+                const int a = tid - 192; R s = 0;
                 _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
                 S.Qu[a] += s;
@@ -388,13 +404,13 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         SW_STAMP(3)
         // wave 0: Eigen's pivoted LDLT of (Quu - 1e-9 I), positivity test, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:366-375);
         // meanwhile the other waves symmetrise Qxx (next phase).  Scratch: the HA block (dead since phase 2) and the reduction buffer.
-        ldlt_inverse_w<M, LDM>(S.Quu, -1e-9, S.LQ, S.HA, reinterpret_cast<int*>(S.red), &SWC.ok);
+        ldlt_inverse_w<M, LDM, R>(S.Quu, R(-1e-9), S.LQ, S.HA, reinterpret_cast<int*>(S.red), &SWC.ok);
         SW_STAMP(4)
         HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) {
                 const int i = e % N, j = e / N;
                 if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
-                    const double s = (i / 16 == j / 16) ? (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2 : CM(S.Qxx, i, j, LDN);
+                    const R s = (i / 16 == j / 16) ? (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2 : CM(S.Qxx, i, j, LDN);
                     CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s;
                 }
             })
@@ -404,16 +420,16 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
         // K = -Quu_inv Qux on the matrix cores (TM x TN tiles over the waves) ; dU = -Quu_inv Qu on the last lanes   (SinglePhase.cpp:379-380)
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;
-              switch (w) { case 0: sweep_tilesK<0, N, M, PY>(S, lane); break; case 1: sweep_tilesK<1, N, M, PY>(S, lane); break;
-                           case 2: sweep_tilesK<2, N, M, PY>(S, lane); break; default: sweep_tilesK<3, N, M, PY>(S, lane); } }
-            if (tid >= NT - M) { const int i = tid - (NT - M); double s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; })
+              switch (w) { case 0: sweep_tilesK<0, N, M, PY, R>(S, lane); break; case 1: sweep_tilesK<1, N, M, PY, R>(S, lane); break;
+                           case 2: sweep_tilesK<2, N, M, PY, R>(S, lane); break; default: sweep_tilesK<3, N, M, PY, R>(S, lane); } }
+            if (tid >= NT - M) { const int i = tid - (NT - M); R s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; })
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
-              switch (w) { case 0: sweep_tiles3<0, N, M, PY>(S, lane); break; case 1: sweep_tiles3<1, N, M, PY>(S, lane); break;
-                           case 2: sweep_tiles3<2, N, M, PY>(S, lane); break; default: sweep_tiles3<3, N, M, PY>(S, lane); } }
-            if (tid >= NT - N) { const int i = tid - (NT - N); double s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
-            else if (tid == NT - N - 1) { double dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
+              switch (w) { case 0: sweep_tiles3<0, N, M, PY, R>(S, lane); break; case 1: sweep_tiles3<1, N, M, PY, R>(S, lane); break;
+                           case 2: sweep_tiles3<2, N, M, PY, R>(S, lane); break; default: sweep_tiles3<3, N, M, PY, R>(S, lane); } }
+            if (tid >= NT - N) { const int i = tid - (NT - N); R s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
+            else if (tid == NT - N - 1) { R dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
             else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); gdU[kk * M + a] = S.dU[a]; })
         SW_STAMP(7)
         HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N);)
@@ -421,7 +437,7 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
     HS_PHASE(NT, if (tid < N) S.def[tid] = gDefect[((size_t)b * (h + 1)) * N + tid];)
-    HS_PHASE(NT, if (tid < N) { double s = S.G[tid]; for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
+    HS_PHASE(NT, if (tid < N) { R s = S.G[tid]; for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; })
     HS_PHASE(NT, if (tid < N) { SWC.xfer[tid] = S.Gn[tid]; gG[((size_t)b * (h + 1)) * N + tid] = S.Gn[tid]; }
              st_mat<NT>(tid, P.H0 + (size_t)b * N * N, S.H, LDN, N, N);)
     return true;
@@ -430,8 +446,8 @@ HD bool riccati_phase(SweepLds& SS, const PhaseDev& P, int b, double reg) {
 // full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, HKD 24/24/0, SRB 12/12/0);
 // returns success, writes dV into S.c.dV1/dV2.  H of the phase being processed sits at the start of the raw block with
 // ld n+1 in every view; the gradient G crosses phase boundaries through S.c.xfer.
-template <int NT>
-HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double reg) {
+template <int NT, class R>
+HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R reg) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
         const PhaseDev& P = ph[i];
@@ -440,25 +456,29 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
             HS_PHASE(NT, for (int e = tid; e < (n + 1) * n; e += NT) S.raw[e] = 0.0; if (tid < n) S.c.xfer[tid] = 0.0;)
         } else {   // impact-aware step: (G,H) <- (Px^T G, Px^T H Px), Px = nn x n, nn <= n  (MultiPhaseDDP.cpp:196-201); once per phase boundary
             const int nn = P.next_n, ldh = nn + 1;
-            double* Hn = S.raw;                          // H of the later phase: nn x nn, ld nn+1
-            double* Px = S.raw + (n + 1) * n;            // scratch in the A / HA regions of the current view (beyond Hn because n >= nn)
-            double* HP = S.raw + 2 * (n + 1) * n;
-            const double* Pxg = P.Px + (size_t)b * nn * n;
-            double gnew = 0.0;
+            R* Hn = S.raw;                          // H of the later phase: nn x nn, ld nn+1
+            R* Px = S.raw + (n + 1) * n;            // scratch in the A / HA regions of the current view (beyond Hn because n >= nn)
+            R* HP = S.raw + 2 * (n + 1) * n;
+            const auto* Pxg = P.Px + (size_t)b * nn * n;
+            R gnew = 0.0;
             HS_PHASE(NT, for (int e = tid; e < nn * n; e += NT) Px[e] = Pxg[e];)
             HS_PHASE(NT,
-                for (int e = tid; e < nn * n; e += NT) { const int r = e % nn, c = e / nn; double s = 0; for (int t = 0; t < nn; t++) s += Hn[r + ldh * t] * Px[t + nn * c]; HP[e] = s; }
-                if (tid >= NT - n) { const int i2 = tid - (NT - n); double s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * i2] * S.c.xfer[t]; S.raw[3 * (n + 1) * n + i2] = s; })
+                for (int e = tid; e < nn * n; e += NT) { const int r = e % nn, c = e / nn; R s = 0; for (int t = 0; t < nn; t++) s += Hn[r + ldh * t] * Px[t + nn * c]; HP[e] = s; }
+                if (tid >= NT - n) { const int i2 = tid - (NT - n); R s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * i2] * S.c.xfer[t]; S.raw[3 * (n + 1) * n + i2] = s; })
             (void)gnew;
             HS_PHASE(NT,
-                for (int e = tid; e < n * n; e += NT) { const int r = e % n, c = e / n; double s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * r] * HP[t + nn * c]; S.raw[r + (n + 1) * c] = s; }
+                for (int e = tid; e < n * n; e += NT) { const int r = e % n, c = e / n; R s = 0; for (int t = 0; t < nn; t++) s += Px[t + nn * r] * HP[t + nn * c]; S.raw[r + (n + 1) * c] = s; }
                 if (tid >= NT - n) S.c.xfer[tid - (NT - n)] = S.raw[3 * (n + 1) * n + tid - (NT - n)];)
         }
         bool ok;
-        switch (P.model) {
-            case HSDDP_MODEL_WB: ok = riccati_phase<NT, 36, 12, 12>(S, P, b, reg); break;
-            case HSDDP_MODEL_SRB: ok = riccati_phase<NT, 12, 12, 0>(S, P, b, reg); break;
-            default: ok = riccati_phase<NT, 24, 24, 0>(S, P, b, reg); break;
+        if constexpr (std::is_same<R, double>::value) {
+            switch (P.model) {
+                case HSDDP_MODEL_WB: ok = riccati_phase<NT, 36, 12, 12, R>(S, P, b, reg); break;
+                case HSDDP_MODEL_SRB: ok = riccati_phase<NT, 12, 12, 0, R>(S, P, b, reg); break;
+                default: ok = riccati_phase<NT, 24, 24, 0, R>(S, P, b, reg); break;
+            }
+        } else {      // fp32 handles hold kinodynamic / single-rigid-body phases only (hsddp_create_ex)
+            if (P.model == HSDDP_MODEL_SRB) ok = riccati_phase<NT, 12, 12, 0, R>(S, P, b, reg); else ok = riccati_phase<NT, 24, 24, 0, R>(S, P, b, reg);
         }
         if (!ok) return false;
     }
@@ -468,19 +488,19 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
 // ---- linear rollout: forward over phases/knots; next knot prefetched into registers (dense ld = rows layouts) ----
 //   rounds: A (rA) | lxx (rA) | B (rB) | K (rB) | luu (rLuu) | [lx(N) lu(M) dU(M) Defect[k+1](N)]
 #define SW_LIN_FETCH(kk_, k_) { \
-    const double* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
+    const HS_GLOBAL R* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { PRE(r) = rec_[RL::oA + NT * r]; PRE(RL::rA + r) = rec_[RL::oLxx + NT * r]; } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? gK[(kk_) * M * N + e] : 0.0; } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? (R)gK[(kk_) * M * N + e] : R(0.0); } \
     _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(2 * RL::rA + 2 * RL::rB + r) = rec_[RL::oLuu + NT * r]; \
-    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? gdU[(kk_) * M + tid - N - M] \
-            : (tid < 2 * N + 2 * M) ? gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : 0.0; }
+    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? (R)gdU[(kk_) * M + tid - N - M] \
+            : (tid < 2 * N + 2 * M) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : R(0.0); }
 #define SW_LIN_COMMIT(p_) { \
-    double* A_ = (p_) ? S.H : S.A; double* Q_ = (p_) ? S.HA : S.Qxx; double* B_ = (p_) ? S.HB : S.B; double* K_ = (p_) ? S.Qux : S.K; double* U_ = (p_) ? S.LQ : S.Quu; \
-    double* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
+    R* A_ = (p_) ? S.H : S.A; R* Q_ = (p_) ? S.HA : S.Qxx; R* B_ = (p_) ? S.HB : S.B; R* K_ = (p_) ? S.Qux : S.K; R* U_ = (p_) ? S.LQ : S.Quu; \
+    R* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { A_[e] = PRE(r); Q_[e] = PRE(RL::rA + r); } } \
     _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) { B_[e] = PRE(2 * RL::rA + r); K_[e] = PRE(2 * RL::rA + RL::rB + r); } } \
     _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) U_[e] = PRE(2 * RL::rA + 2 * RL::rB + r); } \
-    { const double v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
+    { const R v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
       if (tid < N) ((p_) ? S.red : S.Qx)[tid] = v_; else if (tid < N + M) ((p_) ? S.red + 64 : S.Qu)[tid - N] = v_; \
       else if (tid < N + 2 * M) ((p_) ? S.red + 128 : S.dU)[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) ((p_) ? S.red + 192 : S.def)[tid - N - 2 * M] = v_; } }
 
@@ -488,67 +508,67 @@ HD bool riccati_sweep(SweepLds& S, const PhaseDev* ph, int nph, int b, double re
 // Two LDS sets (A, lxx, B, K, luu and the vectors) alternate between knots, so a knot costs two barriers: du = eps dU + K dx, then
 // dx+ = A dx + B du + eps defect together with the commit of the next knot's record into the other set.  The contributions to
 // dV_1 / dV_2 stay in registers (one partial sum per lane) and are added up once per phase.
-template <int NT, int N, int M, int PY>
-HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
-    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY>;
+template <int NT, int N, int M, int PY, class R>
+HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R eps) {
+    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
     static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT, "prefetch registers / lane maps");
-    static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(double), "the partial-sum scratch must not reach dx");
+    static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(R), "the partial-sum scratch must not reach dx");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
-    const auto grec = P.rec; const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX;   // read once (see riccati_phase)
+    const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX;   // read once (see riccati_phase)
     SW_PRE_DECL
 #ifdef HS_HOST_EMU
-    static double acc1_all_[NT], acc2_all_[NT];
+    static R acc1_all_[NT], acc2_all_[NT];
     for (int t = 0; t < NT; t++) { acc1_all_[t] = 0.0; acc2_all_[t] = 0.0; }
 #define ACC1 acc1_all_[tid]
 #define ACC2 acc2_all_[tid]
 #else
-    double acc1_ = 0.0, acc2_ = 0.0;
+    R acc1_ = 0.0, acc2_ = 0.0;
 #define ACC1 acc1_
 #define ACC2 acc2_
 #endif
     // dX[0] = dx_init + eps * Defect[0]
-    HS_PHASE(NT, if (tid < N) { double v = SWC.xfer[tid] + eps * gDefect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; gdX[((size_t)b * (h + 1)) * N + tid] = v; }
+    HS_PHASE(NT, if (tid < N) { R v = SWC.xfer[tid] + eps * gDefect[((size_t)b * (h + 1)) * N + tid]; S.dx[tid] = v; gdX[((size_t)b * (h + 1)) * N + tid] = v; }
              SW_LIN_FETCH((size_t)b * h, 0))
     HS_PHASE_L(NT, SW_LIN_COMMIT(0) if (1 < h) SW_LIN_FETCH((size_t)b * h + 1, 1))
     for (int k = 0; k < h; k++) {
         const size_t kk = (size_t)b * h + k;
         const int p = k & 1;
-        const double* A_ = p ? S.H : S.A; const double* Q_ = p ? S.HA : S.Qxx; const double* B_ = p ? S.HB : S.B; const double* K_ = p ? S.Qux : S.K; const double* U_ = p ? S.LQ : S.Quu;
-        const double* Qx_ = p ? S.red : S.Qx; const double* Qu_ = p ? S.red + 64 : S.Qu; const double* dU_ = p ? S.red + 128 : S.dU; const double* def_ = p ? S.red + 192 : S.def;
-        const double* dxc = p ? S.dxn : S.dx; double* dxw = p ? S.dx : S.dxn;
+        const R* A_ = p ? S.H : S.A; const R* Q_ = p ? S.HA : S.Qxx; const R* B_ = p ? S.HB : S.B; const R* K_ = p ? S.Qux : S.K; const R* U_ = p ? S.LQ : S.Quu;
+        const R* Qx_ = p ? S.red : S.Qx; const R* Qu_ = p ? S.red + 64 : S.Qu; const R* dU_ = p ? S.red + 128 : S.dU; const R* def_ = p ? S.red + 192 : S.def;
+        const R* dxc = p ? S.dxn : S.dx; R* dxw = p ? S.dx : S.dxn;
         // du = eps dU + K dx : row o by the four lanes of quad o
         HS_PHASE_L(NT, SW_QUAD_ROWS(M, {
-            constexpr int CH = (N + 3) / 4; double s = 0;
+            constexpr int CH = (N + 3) / 4; R s = 0;
             _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int j = part * CH + jj; if (j < N) s += CM(K_, o, j, M) * dxc[j]; }
             partial = s; }, { S.du[o] = eps * dU_[o] + total; }))
         HS_PHASE_L(NT,
             // dx+ = [A B] [dx; du] + eps defect and q = lxx dx : row o by quad o, a quarter of the N + M (resp. N) terms per lane
             SW_QUAD_ROWS(N, {
-                constexpr int T = N + M; constexpr int CH = (T + 3) / 4; constexpr int CQ = (N + 3) / 4; double s = 0; double q = 0;
+                constexpr int T = N + M; constexpr int CH = (T + 3) / 4; constexpr int CQ = (N + 3) / 4; R s = 0; R q = 0;
                 _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int t = part * CH + jj; if (t < N) s += CM(A_, o, t, N) * dxc[t]; else if (t < T) s += CM(B_, o, t - N, N) * S.du[t - N]; }
                 _Pragma("unroll") for (int jj = 0; jj < CQ; jj++) { const int j = part * CQ + jj; if (j < N) q += CM(Q_, o, j, N) * dxc[j]; }
                 partial = s; partial2 = q; }, {
-                const double v = total + eps * def_[o];
+                const R v = total + eps * def_[o];
                 dxw[o] = v; gdX[((size_t)b * (h + 1) + k + 1) * N + o] = v;
                 ACC2 += dxc[o] * total2;          // dx^T lxx dx
                 ACC1 += Qx_[o] * dxc[o]; })
             if (tid >= 192 && tid < 192 + M) {
-                const int a = tid - 192; double q = 0;
+                const int a = tid - 192; R q = 0;
                 _Pragma("unroll") for (int j = 0; j < M; j++) q += CM(U_, a, j, M) * S.du[j];
                 ACC2 += S.du[a] * q; ACC1 += Qu_[a] * S.du[a];      // (+ du^T lux dx with lux == 0)
             }
             if (k + 1 < h) { SW_LIN_COMMIT(1 - p) if (k + 2 < h) SW_LIN_FETCH(kk + 2, k + 2) })
     }
-    const double* dxe = (h & 1) ? S.dxn : S.dx;
+    const R* dxe = (h & 1) ? S.dxn : S.dx;
     // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx ; then the per-lane partial sums of the whole phase
     HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
     HS_PHASE(NT, if (tid % SW_QS == 0 && tid / SW_QS < N) { const int o = tid / SW_QS;      // on the lanes that carry the x-part partial sums
-                     double q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, o, j, N) * dxe[j]; ACC2 += dxe[o] * q; ACC1 += P.Phix[(size_t)b * N + o] * dxe[o]; })
-    double* scr = SS.raw;     // 2 x NT partial sums (the matrices are no longer needed; dx / dxn live beyond the first 2 NT doubles of every view)
+                     R q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, o, j, N) * dxe[j]; ACC2 += dxe[o] * q; ACC1 += P.Phix[(size_t)b * N + o] * dxe[o]; })
+    R* scr = SS.raw;     // 2 x NT partial sums (the matrices are no longer needed; dx / dxn live beyond the first 2 NT doubles of every view)
     HS_PHASE(NT, scr[tid] = ACC1; scr[NT + tid] = ACC2;)
-    HS_PHASE(NT, if (tid == 0) { double a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[SW_QS * j]; a2 += scr[NT + SW_QS * j]; }
-                                 double b1 = 0, b2 = 0; for (int j = 0; j < M; j++) { b1 += scr[192 + j]; b2 += scr[NT + 192 + j]; }
+    HS_PHASE(NT, if (tid == 0) { R a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[SW_QS * j]; a2 += scr[NT + SW_QS * j]; }
+                                 R b1 = 0, b2 = 0; for (int j = 0; j < M; j++) { b1 += scr[192 + j]; b2 += scr[NT + 192 + j]; }
                                  SWC.dV1 += a1 + b1; SWC.dV2 += a2; SWC.dV2 += b2; }
              if (tid >= 64 && tid < 64 + N) SWC.xfer[tid - 64] = dxe[tid - 64];)
 #undef ACC1
@@ -556,21 +576,25 @@ HD void linear_phase(SweepLds& SS, const PhaseDev& P, int b, double eps) {
 }
 
 // linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
-template <int NT>
-HD void linear_rollout(SweepLds& S, const PhaseDev* ph, int nph, int b, double eps) {
+template <int NT, class R>
+HD void linear_rollout(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R eps) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; } if (tid < SW_N) S.c.xfer[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
         const PhaseDev& P = ph[i];
         if (i > 0) {   // dx_init = Px * dX_end(prev)   (MultiPhaseDDP.cpp:27-30); xfer holds the previous phase's terminal dX
             const PhaseDev& Pp = ph[i - 1]; const int np = Pp.n, n = P.n;
-            const double* Pxg = Pp.Px + (size_t)b * n * np;
-            HS_PHASE(NT, if (tid < n) { double s = 0; for (int t = 0; t < np; t++) s += Pxg[tid + n * t] * S.c.xfer[t]; S.raw[tid] = s; })
+            const auto* Pxg = Pp.Px + (size_t)b * n * np;
+            HS_PHASE(NT, if (tid < n) { R s = 0; for (int t = 0; t < np; t++) s += Pxg[tid + n * t] * S.c.xfer[t]; S.raw[tid] = s; })
             HS_PHASE(NT, if (tid < n) S.c.xfer[tid] = S.raw[tid];)
         }
-        switch (P.model) {
-            case HSDDP_MODEL_WB: linear_phase<NT, 36, 12, 12>(S, P, b, eps); break;
-            case HSDDP_MODEL_SRB: linear_phase<NT, 12, 12, 0>(S, P, b, eps); break;
-            default: linear_phase<NT, 24, 24, 0>(S, P, b, eps); break;
+        if constexpr (std::is_same<R, double>::value) {
+            switch (P.model) {
+                case HSDDP_MODEL_WB: linear_phase<NT, 36, 12, 12, R>(S, P, b, eps); break;
+                case HSDDP_MODEL_SRB: linear_phase<NT, 12, 12, 0, R>(S, P, b, eps); break;
+                default: linear_phase<NT, 24, 24, 0, R>(S, P, b, eps); break;
+            }
+        } else {
+            if (P.model == HSDDP_MODEL_SRB) linear_phase<NT, 12, 12, 0, R>(S, P, b, eps); else linear_phase<NT, 24, 24, 0, R>(S, P, b, eps);
         }
     }
 }

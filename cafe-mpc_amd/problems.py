@@ -453,13 +453,25 @@ def hkd_trot_problem(schedule=((1, 1, 1, 1), (1, 0, 0, 1), (0, 1, 1, 0), (1, 0, 
     return phases
 
 
-def hkd_ensemble_x0(batch, seed, phases):
-    """Perturbed copies of the first reference state (body pose / twist noise; qdummy kept consistent with the contact set)."""
-    g = SplitMix64(seed)
+def hkd_bound_problem(n_knots=200, dt=0.01, vx=0.5):
+    """BASELINE config 5's workload: HKD 24/24/0 phases in the contact pattern of the shipped bound gait
+    (Reference/Data/bound: 1111(6), then 1100(10) 0000(10) 0011(10) 0000(10) repeating; HKD leg order FR, FL, HR, HL), cut at n_knots."""
+    sched, hor = [(1, 1, 1, 1)], [6]
+    cyc = [((1, 1, 0, 0), 10), ((0, 0, 0, 0), 10), ((0, 0, 1, 1), 10), ((0, 0, 0, 0), 10)]
+    i = 0
+    while sum(hor) < n_knots:
+        c, h = cyc[i % 4]; h = min(h, n_knots - sum(hor))
+        sched.append(c); hor.append(h); i += 1
+    return hkd_trot_problem(schedule=tuple(sched), horizons=tuple(hor), dt=dt, vx=vx, last_next=cyc[i % 4][0])
+
+
+def hkd_ensemble_x0(batch, seed, phases, first=0):
+    """Perturbed copies of the first reference state (body pose / twist noise; qdummy kept consistent with the contact set); problem b
+    draws its 12 numbers from stream position b*12."""
+    g = SplitMix64(seed); g.skip(first * 12)
     x0 = np.tile(phases[0]["bufs"]["xr"][0], (batch, 1))
-    for b in range(batch):
-        for i in range(12):
-            x0[b, i] += (g.next() - 0.5) * (0.06 if i < 6 else 0.2)
+    amp = np.array([0.06] * 6 + [0.2] * 6)
+    x0[:, :12] += (np.array([g.next() for _ in range(batch * 12)]).reshape(batch, 12) - 0.5) * amp
     return x0
 
 

@@ -131,6 +131,16 @@ typedef struct hsddp_handle hsddp_handle_t;
  * SURVEY 8b "Ownership"). */
 int hsddp_create(hsddp_handle_t **out, int n_phases, const hsddp_phase_desc_t *phases,
                  const hsddp_model_param_t *mp, int batch, int device);
+/* the same with a precision flag.  HSDDP_PREC_F32 (kinodynamic HKD 24/24/0 and single-rigid-body phases, HKDModel.h:33-61,
+ * SinglePhase.cpp:566-567): the LQ records (A, B, lxx, luu, lx, lu) are kept in fp32 and the Riccati sweep and the linear rollout run in
+ * fp32 on the fp32 matrix cores (half the HBM bytes of the sweep, a third of its LDS); rollouts, the LQ knot evaluation, the merit
+ * function and every trajectory the ABI hands out stay fp64.  The reference instantiates double only (MultiPhaseDDP.cpp:562): fp32
+ * results are held to a measured tolerance against the fp64 oracle (tests), not to north_star's 1e-6. */
+#define HSDDP_PREC_F64 0
+#define HSDDP_PREC_F32 1
+int hsddp_create_ex(hsddp_handle_t **out, int n_phases, const hsddp_phase_desc_t *phases,
+                    const hsddp_model_param_t *mp, int batch, int device, int precision);
+int hsddp_precision(hsddp_handle_t *h);
 void hsddp_destroy(hsddp_handle_t *h);
 
 /* -- MultiPhaseDDP::set_initial_condition (MultiPhaseDDP.h:43); x0: batch x n(phase 0) */

@@ -39,6 +39,9 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     if (rc != HSDDP_OK) { delete h; return rc; }
     *out = h; return HSDDP_OK;
 }
+// (the precision flag selects the arithmetic of the HIP backend; the checker is the fp64 reference algorithm whatever it says)
+int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int device, int) { return hsddp_create(out, n_phases, phases, mp, batch, device); }
+int hsddp_precision(hsddp_handle_t*) { return HSDDP_PREC_F64; }
 void hsddp_destroy(hsddp_handle_t* h) { delete h; }
 
 int oracle_set_threads(hsddp_handle_t* h, int lq_threads, int problem_threads) {

@@ -23,7 +23,7 @@
 using namespace hs;
 
 struct hsddp_handle {
-    int nph = 0, batch = 0, nslots = 0;
+    int nph = 0, batch = 0, nslots = 0; bool f32 = false;
     std::vector<PhaseDev> ph;
     std::vector<int> sp, sk;
     std::vector<double> x0, cost, dsq, ming, maxh, dV1, dV2, feas, acost;
@@ -41,13 +41,14 @@ struct HostMem {
 
 extern "C" {
 const char* hsddp_backend_name(void) { return "host-lane-emulator"; }
-int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int) {
-    hsddp_handle* h = new hsddp_handle(); h->nph = n_phases; h->batch = batch;
+int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int, int precision) {
+    hsddp_handle* h = new hsddp_handle(); h->nph = n_phases; h->batch = batch; h->f32 = precision == HSDDP_PREC_F32;
     double pd = mp ? mp->psi_dyn : 3.1415, pk = mp ? mp->psi_kin : M_PI; h->md = {cos(pd), sin(pd), cos(pk), sin(pk)};
     h->ph.resize(n_phases); HostMem mem{h};
     for (int i = 0; i < n_phases; i++) {
         if (i > 0 && !phase_chain_ok(phases[i - 1].model, phases[i].model)) return HSDDP_ENOTSUP;
-        int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, batch, h->ph[i], (int)h->sp.size());
+        if (h->f32 && phases[i].model == HSDDP_MODEL_WB) return HSDDP_ENOTSUP;
+        int rc = setup_phase(mem, phases[i], i + 1 < n_phases ? &phases[i + 1] : nullptr, i == n_phases - 1, batch, h->ph[i], (int)h->sp.size(), h->f32);
         if (rc) return rc;
         for (int k = 0; k <= phases[i].horizon; k++) { h->sp.push_back(i); h->sk.push_back(k); }
     }
@@ -56,6 +57,8 @@ int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* p
     h->dV1.assign(batch, 0); h->dV2.assign(batch, 0); h->feas.assign(batch, 0); h->acost.assign(batch, 0); h->fail.assign(batch, 0);
     *out = h; return 0;
 }
+int hsddp_create(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t* phases, const hsddp_model_param_t* mp, int batch, int dev) { return hsddp_create_ex(out, n_phases, phases, mp, batch, dev, HSDDP_PREC_F64); }
+int hsddp_precision(hsddp_handle_t* h) { return h->f32 ? HSDDP_PREC_F32 : HSDDP_PREC_F64; }
 void hsddp_destroy(hsddp_handle_t* h) { if (!h) return; for (void* p : h->allocs) free(p); delete h; }
 int hsddp_set_initial_condition(hsddp_handle_t* h, const double* x0) { memcpy(h->x0.data(), x0, h->x0.size() * 8); return 0; }
 int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const double* Ubar, int per) {
@@ -134,13 +137,21 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
     return 0;
 }
 int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
-    static SweepLds S;
-    for (int b = 0; b < h->batch; b++) { bool ok = riccati_sweep<SW_NT>(S, h->ph.data(), h->nph, b, reg); if (success) success[b] = ok; h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+    static SweepLds S; static SweepLds32 S32;
+    for (int b = 0; b < h->batch; b++) {
+        bool ok;
+        if (h->f32) { ok = riccati_sweep<SW_NT, float>(S32, h->ph.data(), h->nph, b, (float)reg); h->dV1[b] = S32.c.dV1; h->dV2[b] = S32.c.dV2; }
+        else { ok = riccati_sweep<SW_NT, double>(S, h->ph.data(), h->nph, b, reg); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+        if (success) success[b] = ok;
+    }
     return 0;
 }
 int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t*) {
-    static SweepLds S;
-    for (int b = 0; b < h->batch; b++) { linear_rollout<SW_NT>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+    static SweepLds S; static SweepLds32 S32;
+    for (int b = 0; b < h->batch; b++) {
+        if (h->f32) { linear_rollout<SW_NT, float>(S32, h->ph.data(), h->nph, b, (float)eps); h->dV1[b] = S32.c.dV1; h->dV2[b] = S32.c.dV2; }
+        else { linear_rollout<SW_NT, double>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+    }
     return 0;
 }
 int hsddp_update_nominal_trajectory(hsddp_handle_t* h) {
@@ -154,6 +165,13 @@ int hsddp_get_info(hsddp_handle_t* h, hsddp_info_t* info) { for (int b = 0; b < 
 int hsddp_field_shape(hsddp_handle_t* h, int phase, int field, int* count, int* elems) { int st; field_dev(h->ph[phase], field, *count, *elems, st); return 0; }
 int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, double* dst) {
     int count, elems, stride; const double* src = field_dev(h->ph[phase], field, count, elems, stride); size_t sz = (size_t)count * elems;
+    if (h->f32 && stride != elems) {      // a field inside the fp32 LQ record
+        const PhaseDev& P = h->ph[phase];
+        const int off = field == HSDDP_F_A ? P.oA : field == HSDDP_F_B ? P.oB : field == HSDDP_F_C ? P.oC : field == HSDDP_F_D ? P.oD : field == HSDDP_F_LX ? P.oLx : field == HSDDP_F_LU ? P.oLu :
+                        field == HSDDP_F_LY ? P.oLy : field == HSDDP_F_LXX ? P.oLxx : field == HSDDP_F_LUU ? P.oLuu : P.oLyy;
+        for (size_t r = 0; r < (size_t)nb * count; r++) for (int e = 0; e < elems; e++) dst[r * elems + e] = P.rec32[((size_t)b0 * count + r) * stride + off + e];
+        return 0;
+    }
     if (!src) { memset(dst, 0, sz * nb * 8); return 0; }
     for (size_t r = 0; r < (size_t)nb * count; r++) memcpy(dst + r * elems, src + ((size_t)b0 * count + r) * stride, (size_t)elems * 8);
     return 0;

@@ -473,6 +473,66 @@ def test_max_cputime_stops_the_solve(hip_lib, oracle_lib):
     assert len(sg.get_history(0)["cost"]) == 1 == len(so.get_history(0)["cost"])
 
 
+def test_mfma_operand_layouts_on_the_hardware(tmp_path):
+    """The lane -> row maps of the two matrix-core instructions the sweeps rely on (hs_mfma.hpp MfmaT), checked on the device with exact
+    integer data (tools/mfma_*_layout_test.hip)."""
+    import subprocess
+    for name in ("mfma_f64_layout_test", "mfma_f32_layout_test"):
+        exe = tmp_path / name
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tools", name + ".hip"), "-o", str(exe)])
+        out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_fp32_handle_kinodynamic_parity_with_measured_tolerance(hip_lib, oracle_lib):
+    """BASELINE config 5's path: HKD 24/24/0 phases on an HSDDP_PREC_F32 handle (fp32 LQ records, Riccati sweep and linear rollout on
+    v_mfma_f32_16x16x4_f32; rollouts, LQ knot evaluation and the merit function stay fp64) against the fp64 oracle.  The reference is
+    double only, so north_star's 1e-6 on K does not apply; the tolerances below are the measured fp32 error levels of this problem with
+    a factor ~3 of head room: per iterate |dK| <= 1.5e-3 |K|max, expected cost change to 1e-4, states after a full step to 1e-2 of their
+    scale; the full solve must reach the same constraint satisfaction and a cost within 1e-3 of the fp64 one."""
+    phases = pkg.problems.hkd_trot_problem(horizons=(10, 10, 10, 10))
+    x0 = pkg.problems.hkd_ensemble_x0(3, 11, phases)
+    opt = pkg.problems.hkd_ddp_setting()
+    so = pkg.Solver(oracle_lib, phases, batch=3); sg = pkg.Solver(hip_lib, phases, batch=3, precision=pkg.PREC_F32)
+    assert hip_lib.hsddp_precision(sg.h) == pkg.PREC_F32
+    for s_ in (so, sg):
+        for i, p in enumerate(phases):
+            s_.set_nominal(i, p["Xbar"], p["Ubar"])
+        s_.set_initial_condition(x0)
+    tol = {"A": 2e-3, "B": 1e-4, "LXX": 1e-6, "LUU": 1e-6, "LX": 1e-6, "LU": 1e-6, "QUU": 1e-4, "QUX": 1e-3, "K": 1.5e-3, "DU": 2e-3, "G": 3e-4, "DX": 3e-2, "X": 1e-2, "U": 1e-2}
+    for it in range(3):
+        eps = 0.0 if it == 0 else 1.0
+        for s_ in (so, sg):
+            s_.hybrid_rollout(eps, opt); s_.compute_cost(opt)
+            if it == 0:
+                s_.update_nominal_trajectory()
+            s_.LQ_approximation(opt)
+            assert s_.backward_sweep(0.0).all()
+        da, db = so.get_exp_cost_change(), sg.get_exp_cost_change()
+        assert np.allclose(da[0], db[0], rtol=1e-3, atol=1e-3) and np.allclose(da[1], db[1], rtol=1e-3)
+        for s_ in (so, sg):
+            s_.linear_rollout(1.0, opt)
+        for f, r in tol.items():
+            for i in range(len(phases)):
+                a, b = so.field(i, f), sg.field(i, f)
+                if a.size:
+                    assert np.abs(a - b).max() <= r * max(1.0, np.abs(a).max()), (it, f, i, np.abs(a - b).max(), np.abs(a).max())
+    so.close(); sg.close()
+    so = pkg.Solver(oracle_lib, phases, batch=3); sg = pkg.Solver(hip_lib, phases, batch=3, precision=pkg.PREC_F32)
+    for s_ in (so, sg):
+        for i, p in enumerate(phases):
+            s_.set_nominal(i, p["Xbar"], p["Ubar"])
+        s_.set_initial_condition(x0); s_.solve(opt)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    assert (ib["status"] == 0).all() and (ib["max_tconstr"] < 1e-3).all() and (ib["dyn_feas"] < 1e-3).all()
+    assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=1e-3), (ia["actual_cost"], ib["actual_cost"])
+    for i in range(len(phases)):
+        a, b = so.field(i, "XBAR"), sg.field(i, "XBAR")
+        assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(a).max()), (i, np.abs(a - b).max())
+    with pytest.raises(RuntimeError):
+        pkg.Solver(hip_lib, pkg.problems.wb_stance_problem(horizon=3), batch=1, precision=pkg.PREC_F32)      # whole-body phases need fp64
+
+
 def test_flight_phase_and_four_foot_touchdown(hip_lib, oracle_lib):
     """Barrel-roll-like schedule (BarrelRollTO.cpp:70-81 shape): stance -> flight (no contact: free-fall dynamics,
     no GRF constraints) -> stance, i.e. a four-foot touchdown (12-row impulse, the mis-sliced impulse of quirk v)."""
