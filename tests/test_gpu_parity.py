@@ -499,7 +499,8 @@ def test_fp32_handle_kinodynamic_parity_with_measured_tolerance(hip_lib, oracle_
         for i, p in enumerate(phases):
             s_.set_nominal(i, p["Xbar"], p["Ubar"])
         s_.set_initial_condition(x0)
-    tol = {"A": 2e-3, "B": 1e-4, "LXX": 1e-6, "LUU": 1e-6, "LX": 1e-6, "LU": 1e-6, "QUU": 1e-4, "QUX": 1e-3, "K": 1.5e-3, "DU": 2e-3, "G": 3e-4, "DX": 3e-2, "X": 1e-2, "U": 1e-2}
+    # (record fields: fp32 storage of fp64 values, 6e-8 relative, on the first iterate; later iterates inherit the difference of the states)
+    tol = {"A": 2e-3, "B": 1e-4, "LXX": 2e-3, "LUU": 2e-3, "LX": 2e-3, "LU": 2e-3, "QUU": 1e-3, "QUX": 1e-3, "K": 1.5e-3, "DU": 2e-3, "G": 3e-4, "DX": 3e-2, "X": 1e-2, "U": 1e-2}
     for it in range(3):
         eps = 0.0 if it == 0 else 1.0
         for s_ in (so, sg):
@@ -516,7 +517,8 @@ def test_fp32_handle_kinodynamic_parity_with_measured_tolerance(hip_lib, oracle_
             for i in range(len(phases)):
                 a, b = so.field(i, f), sg.field(i, f)
                 if a.size:
-                    assert np.abs(a - b).max() <= r * max(1.0, np.abs(a).max()), (it, f, i, np.abs(a - b).max(), np.abs(a).max())
+                    rr = 1e-6 if (it == 0 and f in ("A", "B", "LXX", "LUU", "LX", "LU")) else r      # first iterate: same fp64 values, stored in fp32
+                    assert np.abs(a - b).max() <= rr * max(1.0, np.abs(a).max()), (it, f, i, float(np.abs(a - b).max()), float(np.abs(a).max()))
     so.close(); sg.close()
     so = pkg.Solver(oracle_lib, phases, batch=3); sg = pkg.Solver(hip_lib, phases, batch=3, precision=pkg.PREC_F32)
     for s_ in (so, sg):
