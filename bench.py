@@ -240,7 +240,8 @@ def main():
                 traffic = json.load(open(tf)).get(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
-                    "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()},
+                    "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
+                    "kernel_units_knots": s.kernel_units(),
                     "whole_iteration": {"alg_bytes_per_knot_iteration": alg_total, "achieved_GBs": alg_total * knots * iters_done / dt / 1e9 / world,
                                         "frac_of_peak": alg_total * knots * iters_done / dt / 1e9 / world / HBM_PEAK_GBS}}
         line = {"metric": METRIC, "value": iters_done / dt, "unit": "DDP iterations/s",

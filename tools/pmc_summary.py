@@ -5,7 +5,6 @@ from collections import defaultdict
 
 tag = sys.argv[1]
 out = f"gpurun_out/{tag}"
-knots_512 = 512 * 204                      # problems x slots per launch of the PMC runs
 
 
 def find(pattern):
@@ -13,11 +12,21 @@ def find(pattern):
     return hits[0] if hits else None
 
 
+def last_json_line(path):
+    if not os.path.exists(path):
+        return None
+    for line in reversed(open(path).read().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
 st = find("stats/**/*kernel_stats.csv")
 if st:
-    shutil.copy(st, f"profiles/{tag}_kernel_stats_batch4096_steps5.csv")
-if os.path.exists(f"{out}/bench.json"):
-    shutil.copy(f"{out}/bench.json", f"profiles/{tag}_bench_batch4096_steps5.json")
+    shutil.copy(st, f"profiles/{tag}_kernel_stats_batch4096_steps20.csv")
+for n in ("steps20", "steps10"):
+    if os.path.exists(f"{out}/bench_{n}.json"):
+        shutil.copy(f"{out}/bench_{n}.json", f"profiles/{tag}_bench_batch4096_{n}.json")
 
 
 def counter_by_kernel(d, counter):
@@ -35,21 +44,31 @@ def counter_by_kernel(d, counter):
 
 fetch, nf = counter_by_kernel("pmc_fetch", "FETCH_SIZE")
 write, nw = counter_by_kernel("pmc_write", "WRITE_SIZE")
-res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (kernel-trace only); command: bench.py --steps 2 --warmup 0 "
-                "--batch 512 --no-cpu-baseline; 512 problems x 204 slots = 104448 knots per launch.  Counters are in KB.  MI355X_MICROARCH.md: on "
-                "gfx950 FETCH_SIZE reads exactly 1/2 of the bytes of a wide (16 B/lane) coalesced stream; these kernels read 8 B/lane "
-                "(uncalibrated width), so both the raw value and the x2 upper bound are listed.", "kernels": {}}
+bl = last_json_line(f"{out}/pmc_fetch_bench.json") or {}
+units = (bl.get("roofline") or {}).get("kernel_units_knots", {})
+# k_rollout (the kernel function) serves both the ordinary rollouts and the probe launches of the batched line search: its unit count is the sum
+units_by_kernel = {"k_rollout": units.get("k_rollout", 0) + units.get("k_ls_probe", 0), "k_lq": units.get("k_lq", 0), "k_sweep": units.get("k_sweep", 0), "k_sweep32": units.get("k_sweep", 0)}
+res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (kernel-trace only); command: bench.py --steps 12 --warmup 0 "
+                "--batch 512 --no-cpu-baseline --no-latency.  Counters are in KB, summed over every launch of a kernel in the run and divided by the knots "
+                "(x line-search candidates) those launches processed (hsddp_get_kernel_units of the same run).  MI355X_MICROARCH.md: on gfx950 "
+                "FETCH_SIZE reads exactly 1/2 of the bytes of a wide (16 B/lane) coalesced stream; these kernels mostly read 8 B/lane, so both the "
+                "raw value and the x2 upper bound are listed.", "kernels": {}}
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
     if not k.startswith("k_"):
         continue
-    fl = fetch.get(k, 0.0) * 1024 / max(nf.get(k, 1), 1); wl = write.get(k, 0.0) * 1024 / max(nw.get(k, 1), 1)
-    res["kernels"][k] = {"fetch_bytes_per_launch_raw": fl, "write_bytes_per_launch": wl, "fetch_bytes_per_knot_raw": fl / knots_512,
-                         "fetch_bytes_per_knot_x2": 2 * fl / knots_512, "write_bytes_per_knot": wl / knots_512}
-    traffic[k] = {"hbm_bytes_per_launch_batch4096_raw": 8 * (fl + wl), "hbm_bytes_per_launch_batch4096_fetch_x2": 8 * (2 * fl + wl),
-                  "source": f"profiles/{tag}_pmc_batch512.json scaled x8 (traffic is linear in the batch)"}
+    fb = fetch.get(k, 0.0) * 1024; wb = write.get(k, 0.0) * 1024
+    u = units_by_kernel.get(k, 0)
+    e = {"launches": nf.get(k, 0), "fetch_bytes_total_raw": fb, "write_bytes_total": wb, "knots_processed": u}
+    if u:
+        e.update({"fetch_bytes_per_knot_raw": fb / u, "fetch_bytes_per_knot_x2": 2 * fb / u, "write_bytes_per_knot": wb / u,
+                  "hbm_bytes_per_knot_raw": (fb + wb) / u, "hbm_bytes_per_knot_fetch_x2": (2 * fb + wb) / u})
+        traffic[k] = {"hbm_bytes_per_knot_raw": (fb + wb) / u, "hbm_bytes_per_knot_fetch_x2": (2 * fb + wb) / u, "source": f"profiles/{tag}_pmc_batch512.json"}
+    res["kernels"][k] = e
+if "k_rollout" in traffic:
+    traffic["k_ls_probe"] = dict(traffic["k_rollout"], note="same kernel function as k_rollout (probe launches): run-wide average per knot x candidate")
 if not res["kernels"]:
     sys.exit(f"no PMC data under {out}: nothing written")
 json.dump(res, open(f"profiles/{tag}_pmc_batch512.json", "w"), indent=1)
-json.dump(traffic, open("profiles/r01_traffic.json", "w"), indent=1)
+json.dump(traffic, open("profiles/r02_traffic.json", "w"), indent=1)
 print("wrote profiles/%s_*" % tag, list(res["kernels"]))
