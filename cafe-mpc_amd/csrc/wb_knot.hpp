@@ -12,8 +12,11 @@
 // Multiple shooting with every knot a shooting node (update_SS_config(h+1), MHPCProblem.cpp:209) makes all
 // knots independent in the rollout, which is what lets the grid be batch x knots.
 //
-// LDS budget: the rollout program uses WbCore only (~15 KB -> up to 8 waves per CU resident); the LQ program adds
-// WbDeriv (inverse mass matrix, KKT inverse, tangent columns, one 36x64 work matrix).
+// LDS budget: the rollout program uses WbCore only (16 KB; two waves per SIMD at 254 registers); the LQ program (two waves per
+// knot) adds WbDeriv: the tangent columns T[18][54], the result rows R[18][36] / a dense 36x36 staging tile, the staging of C, B, D,
+// the UNDAMPED Schur factor for the derivative columns and the barrier derivative tables (40.5 KB per knot).  Neither program forms
+// M^-1 or the KKT inverse: the factors of the forward solve (M = L L^T, X = L^-1 Jc^T, X^T X = L_G L_G^T) serve every right-hand side.
+// A rollout knot also runs as a PROBE of a line-search candidate (wr = false): nothing but the merit partials leaves the wave.
 #pragma once
 #include "hs_types.hpp"
 #include "wb_model.hpp"
