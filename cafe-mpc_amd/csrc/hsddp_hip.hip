@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slo
     }
 }
 
-template <class R>
+template <class R, int SET>
 __device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, const OptDev& opt, ProbState* st, double fixed_reg, int regularized,
                                            int do_linear, double lin_eps, int* success_out) {
     const int b = blockIdx.x;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, cons
         double reg = st[b].reg; int iter = 0;
         while (true) {
             iter++;
-            success = riccati_sweep<SW_NT, R>(S, ph, nph, b, (R)reg);
+            success = riccati_sweep<SW_NT, R, SET>(S, ph, nph, b, (R)reg);
             if (success) break;
             reg = fmax(reg * opt.update_regularization, 1e-3);
             if (reg > 1e2) break;
@@ -250,46 +250,41 @@ __device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, cons
         reg = reg / 20; if (reg < 1e-6) reg = 0;
         if (threadIdx.x == 0) { st[b].reg = reg; st[b].reg_total += iter; st[b].bs_ok = success ? 1 : 0; }
     } else {
-        success = riccati_sweep<SW_NT, R>(S, ph, nph, b, (R)fixed_reg);
+        success = riccati_sweep<SW_NT, R, SET>(S, ph, nph, b, (R)fixed_reg);
         if (threadIdx.x == 0 && success_out) success_out[b] = success ? 1 : 0;
     }
-    if (success && do_linear) linear_rollout<SW_NT, R>(S, ph, nph, b, (R)lin_eps);
+    if (success && do_linear) linear_rollout<SW_NT, R, SET>(S, ph, nph, b, (R)lin_eps);
     __syncthreads();
     if (threadIdx.x == 0) { st[b].dV_1 = S.c.dV1; st[b].dV_2 = S.c.dV2; }
 }
-__global__ void __launch_bounds__(SW_NT, SW_MINB) k_sweep(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
-                                                int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
-    const PhaseDev* ph = ph_;   // (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there)
-    if (masked_out(st[blockIdx.x], mask)) return;
-    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
-    __shared__ SweepLds S;
-    sweep_body<double>(S, ph, nph, opt, st, fixed_reg, regularized, do_linear, lin_eps, success_out);
+// One sweep kernel per (scalar type, model set): the 24-row factor of the kinodynamic model needs twice the registers of the 12-row ones,
+// and a kernel that carries both spills in every instantiation (whole-body kernel alone: 230 registers, no scratch, 150 SGPR spills;
+// with the 24/24/0 phases in the same kernel: 256 + scratch, 850 SGPR spills).
+#define SWEEP_KERNEL(NAME, R_, SET_, LDS_, MINW_) \
+__global__ void __launch_bounds__(SW_NT, MINW_) NAME(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized, \
+                                                     int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) { \
+    const PhaseDev* ph = ph_;   /* (the sweep keeps generic descriptor reads: scalar copies of its fields only add SGPR spills there) */ \
+    if (masked_out(st[blockIdx.x], mask)) return; \
+    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots); \
+    __shared__ LDS_ S; \
+    sweep_body<R_, SET_>(S, ph, nph, opt, st, fixed_reg, regularized, do_linear, lin_eps, success_out); \
 }
+#define LINEAR_KERNEL(NAME, R_, SET_, LDS_, MINW_) \
+__global__ void __launch_bounds__(SW_NT, MINW_) NAME(const PhaseDev* ph_, int nph, ProbState* st, double eps) { \
+    const PhaseDev* ph = ph_; \
+    __shared__ LDS_ S; \
+    linear_rollout<SW_NT, R_, SET_>(S, ph, nph, blockIdx.x, (R_)eps); \
+    __syncthreads(); \
+    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; } \
+}
+SWEEP_KERNEL(k_sweep, double, SW_SET_WB, SweepLds, SW_MINB)           // whole-body (+ SRB tail) phases
+SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLds, SW_MINB)      // kinodynamic 24/24/0 phases, fp64
 // fp32 handles (hsddp_create_ex): fp32 LQ records, every product of the Riccati step on v_mfma_f32_16x16x4_f32, an LDS block a third the size
 // (kinodynamic 24/24/0 and single-rigid-body phases only: SinglePhase.cpp:565-567, HKDModel.h:33-61)
-__global__ void __launch_bounds__(SW_NT, 4) k_sweep32(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized,
-                                                     int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) {
-    const PhaseDev* ph = ph_;
-    if (masked_out(st[blockIdx.x], mask)) return;
-    if (threadIdx.x == 0) atomicAdd(units, (unsigned long long)nknots);
-    __shared__ SweepLds32 S;
-    sweep_body<float>(S, ph, nph, opt, st, fixed_reg, regularized, do_linear, lin_eps, success_out);
-}
-
-__global__ void __launch_bounds__(SW_NT, SW_MINB) k_linear(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
-    const PhaseDev* ph = ph_;
-    __shared__ SweepLds S;
-    linear_rollout<SW_NT, double>(S, ph, nph, blockIdx.x, eps);
-    __syncthreads();
-    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
-}
-__global__ void __launch_bounds__(SW_NT, 4) k_linear32(const PhaseDev* ph_, int nph, ProbState* st, double eps) {
-    const PhaseDev* ph = ph_;
-    __shared__ SweepLds32 S;
-    linear_rollout<SW_NT, float>(S, ph, nph, blockIdx.x, (float)eps);
-    __syncthreads();
-    if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; }
-}
+SWEEP_KERNEL(k_sweep32, float, SW_SET_HKD, SweepLds32, 4)
+LINEAR_KERNEL(k_linear, double, SW_SET_WB, SweepLds, SW_MINB)
+LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLds, SW_MINB)
+LINEAR_KERNEL(k_linear32, float, SW_SET_HKD, SweepLds32, 4)
 
 // receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase / hsddp_reconfigure): one workgroup per (problem, destination knot).
 // Trajectories as SinglePhase::pop_front x shift + push_back_default do (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228); the per-knot
@@ -491,6 +486,7 @@ struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 
 struct hsddp_handle {
     int nph = 0, batch = 0, device = 0, nslots = 0;
+    bool has_hkd = false;             // any kinodynamic phase: the sweep kernels instantiated for {HKD, SRB} serve the handle
     bool f32 = false;                 // HSDDP_PREC_F32: fp32 LQ records + fp32 Riccati sweep / linear rollout (kinodynamic and SRB phases)
     std::vector<PhaseDev> ph;         // host copy (device pointers inside)
     PhaseDev* d_ph = nullptr;
@@ -641,6 +637,7 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
     if (!rc) rc |= dalloc(h, &h->sa.ming, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * h->slots_cap);
     if (rc) { hsddp_destroy(h); return rc; }
     for (int i = 0; i < n_phases; i++) if (!phases[i].shooting && phases[i].model != HSDDP_MODEL_WB) h->probe_ok = false;
+    for (int i = 0; i < n_phases; i++) if (phases[i].model == HSDDP_MODEL_HKD) h->has_hkd = true;
     std::vector<PhaseDev> ss = h->ph; for (auto& q : ss) q.shooting = 0;
     CREATE_CK(hipMemcpy(h->d_ph, h->ph.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
     CREATE_CK(hipMemcpy(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
@@ -738,6 +735,7 @@ int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t*
     }
     h->ph = np; h->nph = n_phases; h->nslots = (int)sp.size();
     h->probe_ok = true; for (int i = 0; i < n_phases; i++) if (!phases[i].shooting && phases[i].model != HSDDP_MODEL_WB) h->probe_ok = false;
+    h->has_hkd = false; for (int i = 0; i < n_phases; i++) if (phases[i].model == HSDDP_MODEL_HKD) h->has_hkd = true;
     h->cache_valid = false;
     if (h->d_cmd_status) { hipFree(h->d_cmd_status); h->d_cmd_status = nullptr; }      // sized by the phase count
     HIPCK(hipGetLastError());
@@ -806,6 +804,7 @@ static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
 static void launch_sweep(hsddp_handle* h, const OptDev& o, int mask, double reg, int regularized, int do_linear, double lin_eps, int* succ) {
     Timed t(h, "k_sweep");
     if (h->f32) hipLaunchKernelGGL(k_sweep32, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
+    else if (h->has_hkd) hipLaunchKernelGGL(k_sweep_hkd, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
     else hipLaunchKernelGGL(k_sweep, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, o, h->d_st, mask, reg, regularized, do_linear, lin_eps, succ, h->d_units + UNIT_SWEEP, h->nslots - h->nph);
 }
 static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, bool count, int iter_ou) {
@@ -936,6 +935,7 @@ int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
     (void)opt; if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device));
     { Timed t(h, "k_linear");
       if (h->f32) hipLaunchKernelGGL(k_linear32, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps);
+      else if (h->has_hkd) hipLaunchKernelGGL(k_linear_hkd, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps);
       else hipLaunchKernelGGL(k_linear, dim3(h->batch), dim3(SW_NT), 0, h->stream, h->d_ph, h->nph, h->d_st, eps); }
     HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError()); return HSDDP_OK;
 }

@@ -29,6 +29,7 @@
 namespace hs {
 
 constexpr int SW_NT = 256;
+constexpr int SW_SET_WB = 0, SW_SET_HKD = 1;      // model sets a sweep kernel is instantiated for: {whole body, SRB} / {kinodynamic, SRB}
 constexpr int SW_N = 36;    // largest state dimension of any model
 constexpr int SW_PRE = 20;  // prefetch registers per thread
 #ifndef SW_UNROLL_N
@@ -446,7 +447,7 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
 // full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, HKD 24/24/0, SRB 12/12/0);
 // returns success, writes dV into S.c.dV1/dV2.  H of the phase being processed sits at the start of the raw block with
 // ld n+1 in every view; the gradient G crosses phase boundaries through S.c.xfer.
-template <int NT, class R>
+template <int NT, class R, int SET>
 HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R reg) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
@@ -471,13 +472,11 @@ HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int n
                 if (tid >= NT - n) S.c.xfer[tid - (NT - n)] = S.raw[3 * (n + 1) * n + tid - (NT - n)];)
         }
         bool ok;
-        if constexpr (std::is_same<R, double>::value) {
-            switch (P.model) {
-                case HSDDP_MODEL_WB: ok = riccati_phase<NT, 36, 12, 12, R>(S, P, b, reg); break;
-                case HSDDP_MODEL_SRB: ok = riccati_phase<NT, 12, 12, 0, R>(S, P, b, reg); break;
-                default: ok = riccati_phase<NT, 24, 24, 0, R>(S, P, b, reg); break;
-            }
-        } else {      // fp32 handles hold kinodynamic / single-rigid-body phases only (hsddp_create_ex)
+        // (the kernels are instantiated per model SET: the 24-row factor of the kinodynamic model needs twice the registers of the 12-row
+        //  ones, and a kernel that carries both spills in every instantiation)
+        if constexpr (SET == SW_SET_WB) {
+            if (P.model == HSDDP_MODEL_WB) ok = riccati_phase<NT, 36, 12, 12, R>(S, P, b, reg); else ok = riccati_phase<NT, 12, 12, 0, R>(S, P, b, reg);
+        } else {
             if (P.model == HSDDP_MODEL_SRB) ok = riccati_phase<NT, 12, 12, 0, R>(S, P, b, reg); else ok = riccati_phase<NT, 24, 24, 0, R>(S, P, b, reg);
         }
         if (!ok) return false;
@@ -576,7 +575,7 @@ HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b,
 }
 
 // linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
-template <int NT, class R>
+template <int NT, class R, int SET>
 HD void linear_rollout(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R eps) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; } if (tid < SW_N) S.c.xfer[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
@@ -587,12 +586,8 @@ HD void linear_rollout(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int 
             HS_PHASE(NT, if (tid < n) { R s = 0; for (int t = 0; t < np; t++) s += Pxg[tid + n * t] * S.c.xfer[t]; S.raw[tid] = s; })
             HS_PHASE(NT, if (tid < n) S.c.xfer[tid] = S.raw[tid];)
         }
-        if constexpr (std::is_same<R, double>::value) {
-            switch (P.model) {
-                case HSDDP_MODEL_WB: linear_phase<NT, 36, 12, 12, R>(S, P, b, eps); break;
-                case HSDDP_MODEL_SRB: linear_phase<NT, 12, 12, 0, R>(S, P, b, eps); break;
-                default: linear_phase<NT, 24, 24, 0, R>(S, P, b, eps); break;
-            }
+        if constexpr (SET == SW_SET_WB) {
+            if (P.model == HSDDP_MODEL_WB) linear_phase<NT, 36, 12, 12, R>(S, P, b, eps); else linear_phase<NT, 12, 12, 0, R>(S, P, b, eps);
         } else {
             if (P.model == HSDDP_MODEL_SRB) linear_phase<NT, 12, 12, 0, R>(S, P, b, eps); else linear_phase<NT, 24, 24, 0, R>(S, P, b, eps);
         }
