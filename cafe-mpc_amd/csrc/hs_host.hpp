@@ -70,7 +70,8 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     al(&P.Quu, B * hh * m * m);
     {   // record layout: the runtime twin of RecLayout<N,M,PY> (hs_types.hpp)
         auto rnd = [](size_t x) { return (x + 255) / 256 * 256; };
-        const size_t oA = 0, oLxx = oA + rnd(n * n), oB = oLxx + rnd(n * n), oC = oB + rnd(n * m), oD = oC + rnd(py * n), oLuu = oD + rnd(py * m),
+        const size_t ar = (size_t)rec_arows((int)n);      // stored rows of A and B (whole body: the lower 18)
+        const size_t oA = 0, oLxx = oA + rnd(ar * n), oB = oLxx + rnd(n * n), oC = oB + rnd(ar * m), oD = oC + rnd(py * n), oLuu = oD + rnd(py * m),
                      oLyy = oLuu + rnd(m * m), oLx = oLyy + rnd(py * py), oLu = oLx + n, oLy = oLu + m, size = oLx + rnd(n + m + py);
         P.rs = (int)size;
         P.oA = (int)oA; P.oLxx = (int)oLxx; P.oB = (int)oB; P.oC = (int)oC; P.oD = (int)oD; P.oLuu = (int)oLuu; P.oLyy = (int)oLyy; P.oLx = (int)oLx; P.oLu = (int)oLu; P.oLy = (int)oLy;
@@ -134,6 +135,19 @@ inline const double* field_dev(const PhaseDev& P, int f, int& count, int& elems)
         case HSDDP_F_AL_SIGMA: count = 1; elems = P.nt; return P.sigma;
         case HSDDP_F_AL_LAMBDA: count = 1; elems = P.nt; return P.lambda;
         default: count = 0; elems = 0; return nullptr;
+    }
+}
+
+// Whole-body A / B as the ABI hands them out (36 x 36 / 36 x 12, column-major) from the stored lower halves (RecLayout): the upper
+// rows are the forward-Euler identities A = [I, dt I; ...], B = [0; ...] (WBM.cpp:68, 122-125).
+inline bool wb_structured(const PhaseDev& P, int f) { return P.model == HSDDP_MODEL_WB && (f == HSDDP_F_A || f == HSDDP_F_B); }
+inline void wb_expand_ab(int f, double dt, const double* stored, double* full) {
+    const int cols = f == HSDDP_F_A ? 36 : 12;
+    for (int c = 0; c < cols; c++) for (int r = 0; r < 36; r++) {
+        double v;
+        if (r >= 18) v = stored[(r - 18) + 18 * c];
+        else v = f == HSDDP_F_A ? ((c == r ? 1.0 : 0.0) + (c == 18 + r ? dt : 0.0)) : 0.0;
+        full[r + 36 * c] = v;
     }
 }
 

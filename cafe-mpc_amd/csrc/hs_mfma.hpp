@@ -36,6 +36,15 @@ template <class R = double> struct MTileT {
     bool TB = false;
     bool TC = false;      // C(i,j) (and Cin) at C[j + ldc*i] instead of C[i + ldc*j]
     R dadd = 0.0;    // added to the entries C(i,i) of the tile's block (i.e. where the absolute row equals the absolute column)
+    // structured operand [I, s I] folded in as an addend (whole-body A = [I, dt I; A21, A22]: the products run over the lower rows only):
+    //   tmode 1 (H [I, s I]):    C(i,j) += j < tsplit ? T(i,j) : tscale * T(i, j - tsplit)
+    //   tmode 2 ([I, s I]^T HA): C(i,j) += i < tsplit ? T(i,j) : tscale * T(i - tsplit, j)          T(i,j) = T[i + ldt*j]
+    const R* T = nullptr; int ldt = 0; int tmode = 0; int tsplit = 0; R tscale = 0.0;
+    HD R top(int i, int j) const {
+        if (tmode == 1) return j < tsplit ? T[i + ldt * j] : tscale * T[i + ldt * (j - tsplit)];
+        if (tmode == 2) return i < tsplit ? T[i + ldt * j] : tscale * T[(i - tsplit) + ldt * j];
+        return R(0.0);
+    }
 };
 using MTile = MTileT<double>;
 template <int NTL, int KMAX, int KMAX2, class R>
@@ -47,6 +56,7 @@ HD void mfma_tiles(int lane, const MTileT<R>* td) {
         const MTileT<R>& T = td[t];
         for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
             R s = T.Cin ? (T.TC ? T.Cin[j + T.ldcin * i] : T.Cin[i + T.ldcin * j]) : 0.0;
+            s += T.top(i, j);
             for (int k = 0; k < T.K; k++) s += (T.TA ? T.A[k + T.lda * i] : T.A[i + T.lda * k]) * (T.TB ? T.B[j + T.ldb * k] : T.B[k + T.ldb * j]);
             for (int k = 0; k < T.K2; k++) s += T.A2[k + T.lda2 * i] * T.B2[k + T.ldb2 * j];
             res[t][(i - T.i0) + 16 * (j - T.j0)] = s;
@@ -64,7 +74,8 @@ HD void mfma_tiles(int lane, const MTileT<R>* td) {
     typename MfmaT<R>::acc c[NTL];
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
         const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0; }
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0;
+            if (td[t].tmode != 0 && row < td[t].M_ && j < td[t].N_) c[t][r] += td[t].top(row, j); }
     }
     _Pragma("unroll") for (int kg = 0; kg < KMAX / 4; kg++) {
         _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K) {

@@ -9,13 +9,18 @@ constexpr int MAXN = 36, MAXM = 24, MAXP = 12, MAXG = 96;   // MAXG: 24 torque +
 // doubles so that a 256-thread workgroup streams the record in rounds that each lie inside ONE sub-array.
 //   A | lxx | B | C | D | luu | lyy | [lx lu ly]
 constexpr int rec_rnd(int x) { return (x + 255) / 256 * 256; }
+// Rows of A and B that are DATA.  The whole-body discretisation is A = [I, dt I; A21, A22], B = [0; B2] (WBM.cpp:68, 122-125: forward Euler of
+// q' = v): only the lower 18 rows are stored (column-major, 18 rows per column) and the sweeps use the structure (half the inner dimension of
+// every product with A or B).  SRB / HKD: dense.
+constexpr int rec_arows(int N) { return N == 36 ? 18 : N; }
 template <int N, int M, int PY> struct RecLayout {
-    static constexpr int oA = 0, oLxx = oA + rec_rnd(N * N), oB = oLxx + rec_rnd(N * N), oC = oB + rec_rnd(N * M), oD = oC + rec_rnd(PY * N),
+    static constexpr int AR = rec_arows(N);
+    static constexpr int oA = 0, oLxx = oA + rec_rnd(AR * N), oB = oLxx + rec_rnd(N * N), oC = oB + rec_rnd(AR * M), oD = oC + rec_rnd(PY * N),
                          oLuu = oD + rec_rnd(PY * M), oLyy = oLuu + rec_rnd(M * M), oLx = oLyy + rec_rnd(PY * PY), oLu = oLx + N, oLy = oLu + M,
                          size = oLx + rec_rnd(N + M + PY);
-    static constexpr int rA = rec_rnd(N * N) / 256, rB = rec_rnd(N * M) / 256, rC = rec_rnd(PY * N) / 256, rD = rec_rnd(PY * M) / 256,
+    static constexpr int rA = rec_rnd(AR * N) / 256, rQ = rec_rnd(N * N) / 256, rB = rec_rnd(AR * M) / 256, rC = rec_rnd(PY * N) / 256, rD = rec_rnd(PY * M) / 256,
                          rLuu = rec_rnd(M * M) / 256, rLyy = rec_rnd(PY * PY) / 256;
-    static constexpr int rounds = 2 * rA + rB + rC + rD + rLuu + rLyy;   // + 1 round for the vectors
+    static constexpr int rounds = rA + rQ + rB + rC + rD + rLuu + rLyy;   // + 1 round for the vectors
 };
 
 // Contact-solve cache (whole-body knots): what the LAST rollout of a knot computed at (X[k], U[k]) and the LQ approximation would

@@ -998,6 +998,13 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
     }
     if (!src) { memset(dst, 0, sz * nb * 8); return HSDDP_OK; }
     if (sz == 0 || nb == 0) return HSDDP_OK;
+    if (wb_structured(h->ph[phase], field)) {      // the record holds the lower 18 rows only: the identities of the upper rows are filled in here
+        const int st = field == HSDDP_F_A ? 648 : 216;
+        std::vector<double> tmp((size_t)st * nb * count);
+        HIPCK(hipMemcpy2D(tmp.data(), (size_t)st * 8, src + (size_t)b0 * count * stride, (size_t)stride * 8, (size_t)st * 8, (size_t)nb * count, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < (size_t)nb * count; r++) wb_expand_ab(field, h->ph[phase].dt, tmp.data() + r * st, dst + r * elems);
+        return HSDDP_OK;
+    }
     if (stride == elems) HIPCK(hipMemcpy(dst, src + (size_t)b0 * sz, sz * nb * 8, hipMemcpyDeviceToHost));
     else HIPCK(hipMemcpy2D(dst, (size_t)elems * 8, src + (size_t)b0 * count * stride, (size_t)stride * 8, (size_t)elems * 8, (size_t)nb * count, hipMemcpyDeviceToHost));
     return HSDDP_OK;

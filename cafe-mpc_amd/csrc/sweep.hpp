@@ -49,8 +49,9 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 // R: the scalar the sweep computes in - double, or float for the fp32 handles of hsddp_create_ex (fp32 LQ records, v_mfma_f32_16x16x4_f32)
 template <int N, int M, int PY, class R = double> struct SweepLdsT {
     static constexpr int LDN = N + 1, LDM = (M > PY ? M : PY) + 1, PYd = PY > 0 ? PY : 1;
-    R H[LDN * N], A[LDN * N], HA[LDN * N], Qxx[LDN * N];
-    R B[LDN * M], HB[LDN * M];
+    static constexpr int AR = rec_arows(N), LDA = AR + 1, A0 = N - AR;      // A, B: the stored (lower AR) rows, i.e. rows A0.. of the full matrices
+    R H[LDN * N], A[LDA * N], HA[LDN * N], Qxx[LDN * N];
+    R B[LDA * M], HB[LDN * M];
     R Qux[LDM * N], K[LDM * N], C[PY > 0 ? LDM * N : 1], lC[PY > 0 ? LDM * N : 1];
     R D[PY > 0 ? LDM * M : 1], lD[PY > 0 ? LDM * M : 1], lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M], LQ[LDM * M];
     R G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N], rdQ[M];
@@ -262,12 +263,14 @@ template <int NT, class TD, class TS> HD void st_mat(int tid, TD* dst, const TS*
     PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : R(0.0); }
 #define SW_RICCATI_COMMIT() { \
     constexpr int PYd = PY > 0 ? PY : 1; \
-    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { S.A[(e % N) + LDN * (e / N)] = PRE(r); S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) S.B[(e % N) + LDN * (e / N)] = PRE(2 * RL::rA + r); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rC; r++) { const int e = tid + NT * r; if (e < PY * N) S.C[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + r); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rD; r++) { const int e = tid + NT * r; if (e < PY * M) S.D[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + RL::rC + r); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) S.Quu[(e % M) + LDM * (e / M)] = PRE(2 * RL::rA + RL::rB + RL::rC + RL::rD + r); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rLyy; r++) { const int e = tid + NT * r; if (e < PY * PY) S.lyy[(e % PYd) + LDM * (e / PYd)] = PRE(2 * RL::rA + RL::rB + RL::rC + RL::rD + RL::rLuu + r); } \
+    constexpr int AR = RL::AR; constexpr int LDA = AR + 1; \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < AR * N) S.A[(e % AR) + LDA * (e / AR)] = PRE(r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) { const int e = tid + NT * r; if (e < N * N) S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < AR * M) S.B[(e % AR) + LDA * (e / AR)] = PRE(RL::rA + RL::rQ + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rC; r++) { const int e = tid + NT * r; if (e < PY * N) S.C[(e % PYd) + LDM * (e / PYd)] = PRE(RL::rA + RL::rQ + RL::rB + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rD; r++) { const int e = tid + NT * r; if (e < PY * M) S.D[(e % PYd) + LDM * (e / PYd)] = PRE(RL::rA + RL::rQ + RL::rB + RL::rC + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) S.Quu[(e % M) + LDM * (e / M)] = PRE(RL::rA + RL::rQ + RL::rB + RL::rC + RL::rD + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLyy; r++) { const int e = tid + NT * r; if (e < PY * PY) S.lyy[(e % PYd) + LDM * (e / PYd)] = PRE(RL::rA + RL::rQ + RL::rB + RL::rC + RL::rD + RL::rLuu + r); } \
     if (tid < N) S.Qx[tid] = PRE(RL::rounds); else if (tid < N + M) S.Qu[tid - N] = PRE(RL::rounds); else if (tid < N + M + PY) S.ly[tid - N - M] = PRE(RL::rounds); \
     else if (tid < 2 * N + M + PY) S.def[tid - N - M - PY] = PRE(RL::rounds); }
 
@@ -279,8 +282,8 @@ template <> HD const HS_GLOBAL float* rec_of<float>(const PhaseDev& P) { return 
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
 template <int W, int N, int M, int PY, class R>
-HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane) {
-    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM;
+HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane, R dt) {
+    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM, AR = SweepLdsT<N, M, PY, R>::AR, LDA = SweepLdsT<N, M, PY, R>::LDA, A0 = SweepLdsT<N, M, PY, R>::A0;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16, TPd = TP > 0 ? TP : 1;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
     constexpr int NTL = (t4 - W + 3) / 4;
@@ -288,16 +291,18 @@ HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane) {
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        if (t < t1) td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H, LDN, S.A, LDN, N, false, nullptr, 0, nullptr, 0, 0};
-        else if (t < t2) td[q] = MTileT<R>{S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H, LDN, S.B, LDN, N, false, nullptr, 0, nullptr, 0, 0};
+        // HA = H A = H(:, A0:) A_low (+ H [I, dt I] when the upper rows of A are the forward-Euler identities) ; HB = H(:, A0:) B_low
+        if (t < t1) { td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H + LDN * A0, LDN, S.A, LDA, AR, false, nullptr, 0, nullptr, 0, 0};
+                      if (A0 > 0) { td[q].T = S.H; td[q].ldt = LDN; td[q].tmode = 1; td[q].tsplit = A0; td[q].tscale = dt; } }
+        else if (t < t2) td[q] = MTileT<R>{S.HB, LDN, nullptr, 0, 16 * ((t - t1) % TN), 16 * ((t - t1) / TN), N, M, S.H + LDN * A0, LDN, S.B, LDA, AR, false, nullptr, 0, nullptr, 0, 0};
         else if (t < t3) td[q] = MTileT<R>{S.lC, LDM, nullptr, 0, 16 * ((t - t2) % TPd), 16 * ((t - t2) / TPd), PY, N, S.lyy, LDM, S.C, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
         else td[q] = MTileT<R>{S.lD, LDM, nullptr, 0, 16 * ((t - t3) % TPd), 16 * ((t - t3) / TPd), PY, M, S.lyy, LDM, S.D, LDM, PY, false, nullptr, 0, nullptr, 0, 0};
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, 0, R>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), ((AR > PY ? AR : PY) + 3) / 4 * 4, 0, R>(lane, td);
 }
 template <int W, int N, int M, int PY, class R>
-HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg) {
-    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM;
+HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
+    constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM, AR = SweepLdsT<N, M, PY, R>::AR, LDA = SweepLdsT<N, M, PY, R>::LDA, A0 = SweepLdsT<N, M, PY, R>::A0;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
     // body), the symmetrisation step of the reference (SinglePhase.cpp:376) fills the rest
@@ -309,11 +314,13 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg) {
         const int t = W + 4 * q;
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
-        if (t < t1) { td[q] = MTileT<R>{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDN, S.HA, LDN, N, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg; }     // regularisation on Qxx as well: quirk x
-        else if (t < t2) td[q] = MTileT<R>{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDN, S.HA, LDN, N, true, S.D, LDM, S.lC, LDM, PY};
-        else { td[q] = MTileT<R>{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDN, S.HB, LDN, N, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
+        // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
+        if (t < t1) { td[q] = MTileT<R>{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDA, S.HA + A0, LDN, AR, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg;     // regularisation on Qxx as well: quirk x
+                      if (A0 > 0) { td[q].T = S.HA; td[q].ldt = LDN; td[q].tmode = 2; td[q].tsplit = A0; td[q].tscale = dt; } }
+        else if (t < t2) td[q] = MTileT<R>{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDA, S.HA + A0, LDN, AR, true, S.D, LDM, S.lC, LDM, PY};
+        else { td[q] = MTileT<R>{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDA, S.HB + A0, LDN, AR, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
     }
-    mfma_tiles<(NTL > 0 ? NTL : 1), (N + 3) / 4 * 4, (PY + 3) / 4 * 4, R>(lane, td);
+    mfma_tiles<(NTL > 0 ? NTL : 1), (AR + 3) / 4 * 4, (PY + 3) / 4 * 4, R>(lane, td);
 }
 
 // H = Qxx + Qux^T K : the TN x TN tiles dealt round-robin, a wave's tiles interleaved (their short accumulation chains overlap)
@@ -351,10 +358,10 @@ template <int NT, int N, int M, int PY, class R>
 HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R reg) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
-    constexpr int LDN = ST::LDN, LDM = ST::LDM;
+    constexpr int LDN = ST::LDN, LDM = ST::LDM, AR = ST::AR, LDA = ST::LDA, A0 = ST::A0;
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
-    const int h = P.h;
+    const int h = P.h; const R dtR = (R)P.dt;
     // trajectory pointers of the phase, read ONCE: a descriptor field fetched inside the knot loop is a vector load whose wait
     // (vmcnt(0)) would also drain the record prefetch that is meant to stay in flight for a whole knot
     const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gQu = P.Qu; const auto gQuu = P.Quu; const auto gQux = P.Qux;
@@ -374,8 +381,8 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
         // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane); break;
-                         case 2: sweep_tiles1<2, N, M, PY, R>(S, lane); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane); }
+            switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane, dtR); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane, dtR); break;
+                         case 2: sweep_tiles1<2, N, M, PY, R>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane, dtR); }
             if (tid < N) { R s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
         })
         SW_STAMP(1)
@@ -383,17 +390,18 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles2<0, N, M, PY, R>(S, lane, reg); break; case 1: sweep_tiles2<1, N, M, PY, R>(S, lane, reg); break;
-                         case 2: sweep_tiles2<2, N, M, PY, R>(S, lane, reg); break; default: sweep_tiles2<3, N, M, PY, R>(S, lane, reg); }
+            switch (w) { case 0: sweep_tiles2<0, N, M, PY, R>(S, lane, reg, dtR); break; case 1: sweep_tiles2<1, N, M, PY, R>(S, lane, reg, dtR); break;
+                         case 2: sweep_tiles2<2, N, M, PY, R>(S, lane, reg, dtR); break; default: sweep_tiles2<3, N, M, PY, R>(S, lane, reg, dtR); }
             // the two mat-vec chains ride on waves 2 and 3, which carry two tiles each in this phase (waves 0 and 1: three)
             if (tid >= 128 && tid < 128 + N) {
                 const int i = tid - 128; R s = 0;
-                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.A, t, i, LDN) * S.Gn[t];
+                if (A0 > 0) s = (i < A0) ? S.Gn[i] : dtR * S.Gn[i - A0];       // [I, dt I]^T Gn(:A0): the upper rows of the whole-body A
+                _Pragma("unroll 6") for (int t = 0; t < AR; t++) s += CM(S.A, t, i, LDA) * S.Gn[A0 + t];
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
                 S.Qx[i] += s;
             } else if (tid >= 192 && tid < 192 + M) {
                 const int a = tid - 192; R s = 0;
-                _Pragma("unroll 6") for (int t = 0; t < N; t++) s += CM(S.B, t, a, LDN) * S.Gn[t];
+                _Pragma("unroll 6") for (int t = 0; t < AR; t++) s += CM(S.B, t, a, LDA) * S.Gn[A0 + t];
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
                 S.Qu[a] += s;
             }
@@ -485,21 +493,25 @@ HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int n
 }
 
 // ---- linear rollout: forward over phases/knots; next knot prefetched into registers (dense ld = rows layouts) ----
-//   rounds: A (rA) | lxx (rA) | B (rB) | K (rB) | luu (rLuu) | [lx(N) lu(M) dU(M) Defect[k+1](N)]
+//   rounds: A (rA) | lxx (rQ) | B (rB) | K (rK) | luu (rLuu) | [lx(N) lu(M) dU(M) Defect[k+1](N)]
 #define SW_LIN_FETCH(kk_, k_) { \
     const HS_GLOBAL R* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
-    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { PRE(r) = rec_[RL::oA + NT * r]; PRE(RL::rA + r) = rec_[RL::oLxx + NT * r]; } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; PRE(2 * RL::rA + r) = rec_[RL::oB + NT * r]; PRE(2 * RL::rA + RL::rB + r) = (e < M * N) ? (R)gK[(kk_) * M * N + e] : R(0.0); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(2 * RL::rA + 2 * RL::rB + r) = rec_[RL::oLuu + NT * r]; \
-    PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? (R)gdU[(kk_) * M + tid - N - M] \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) PRE(r) = rec_[RL::oA + NT * r]; \
+    _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) PRE(RL::rA + r) = rec_[RL::oLxx + NT * r]; \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) PRE(RL::rA + RL::rQ + r) = rec_[RL::oB + NT * r]; \
+    _Pragma("unroll") for (int r = 0; r < rK; r++) { const int e = tid + NT * r; PRE(RL::rA + RL::rQ + RL::rB + r) = (e < M * N) ? (R)gK[(kk_) * M * N + e] : R(0.0); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) PRE(RL::rA + RL::rQ + RL::rB + rK + r) = rec_[RL::oLuu + NT * r]; \
+    PRE(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? (R)gdU[(kk_) * M + tid - N - M] \
             : (tid < 2 * N + 2 * M) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : R(0.0); }
 #define SW_LIN_COMMIT(p_) { \
     R* A_ = (p_) ? S.H : S.A; R* Q_ = (p_) ? S.HA : S.Qxx; R* B_ = (p_) ? S.HB : S.B; R* K_ = (p_) ? S.Qux : S.K; R* U_ = (p_) ? S.LQ : S.Quu; \
     R* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
-    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < N * N) { A_[e] = PRE(r); Q_[e] = PRE(RL::rA + r); } } \
-    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < N * M) { B_[e] = PRE(2 * RL::rA + r); K_[e] = PRE(2 * RL::rA + RL::rB + r); } } \
-    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) U_[e] = PRE(2 * RL::rA + 2 * RL::rB + r); } \
-    { const R v_ = PRE(2 * RL::rA + 2 * RL::rB + RL::rLuu); \
+    _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < AR * N) A_[e] = PRE(r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) { const int e = tid + NT * r; if (e < N * N) Q_[e] = PRE(RL::rA + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < AR * M) B_[e] = PRE(RL::rA + RL::rQ + r); } \
+    _Pragma("unroll") for (int r = 0; r < rK; r++) { const int e = tid + NT * r; if (e < N * M) K_[e] = PRE(RL::rA + RL::rQ + RL::rB + r); } \
+    _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) U_[e] = PRE(RL::rA + RL::rQ + RL::rB + rK + r); } \
+    { const R v_ = PRE(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu); \
       if (tid < N) ((p_) ? S.red : S.Qx)[tid] = v_; else if (tid < N + M) ((p_) ? S.red + 64 : S.Qu)[tid - N] = v_; \
       else if (tid < N + 2 * M) ((p_) ? S.red + 128 : S.dU)[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) ((p_) ? S.red + 192 : S.def)[tid - N - 2 * M] = v_; } }
 
@@ -510,7 +522,10 @@ HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int n
 template <int NT, int N, int M, int PY, class R>
 HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R eps) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
-    static_assert(2 * RL::rA + 2 * RL::rB + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT, "prefetch registers / lane maps");
+    constexpr int rK = rec_rnd(M * N) / 256, AR = ST::AR, A0 = ST::A0;
+    static_assert(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT, "prefetch registers / lane maps");
+    static_assert(sizeof(ST::A) / sizeof(R) >= (size_t)AR * N && sizeof(ST::B) / sizeof(R) >= (size_t)AR * M, "dense copies of the stored rows fit the padded buffers");
+    const R dtR = (R)P.dt;
     static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(R), "the partial-sum scratch must not reach dx");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
@@ -545,7 +560,9 @@ HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b,
             // dx+ = [A B] [dx; du] + eps defect and q = lxx dx : row o by quad o, a quarter of the N + M (resp. N) terms per lane
             SW_QUAD_ROWS(N, {
                 constexpr int T = N + M; constexpr int CH = (T + 3) / 4; constexpr int CQ = (N + 3) / 4; R s = 0; R q = 0;
-                _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int t = part * CH + jj; if (t < N) s += CM(A_, o, t, N) * dxc[t]; else if (t < T) s += CM(B_, o, t - N, N) * S.du[t - N]; }
+                if (o >= A0) {      // a stored row of [A B]
+                    _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int t = part * CH + jj; if (t < N) s += CM(A_, o - A0, t, AR) * dxc[t]; else if (t < T) s += CM(B_, o - A0, t - N, AR) * S.du[t - N]; }
+                } else if (part == 0) s = dxc[o] + dtR * dxc[A0 + o];      // upper rows of the whole-body A = [I, dt I], B = 0
                 _Pragma("unroll") for (int jj = 0; jj < CQ; jj++) { const int j = part * CQ + jj; if (j < N) q += CM(Q_, o, j, N) * dxc[j]; }
                 partial = s; partial2 = q; }, {
                 const R v = total + eps * def_[o];

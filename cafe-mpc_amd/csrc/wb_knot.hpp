@@ -964,9 +964,9 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         // wave 1 has been done for a while when wave 0 leaves the column solves: both copy A, B, C, D out
         hs_phase_sync_all<NT>();
         HS_PHASE_L(NT,
-            store_image<NT, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
+            store_image<NT, 648, 18>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return D.W[WR0 + r * 36 + c]; });     /* rows 18..35 of A (the upper rows are [I, dt I]) */
             store_image<NT, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
-            store_image<NT, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
+            store_image<NT, 216, 18>(P.B + kk * P.rs, tid, [&](int e, int, int) { return D.stB()[e]; });     /* rows 18..35 of B (the upper rows are zero) */
             store_image<NT, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
         LQ_STAMP(4)
         return;
@@ -1005,11 +1005,11 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         }
     })
     LQ_STAMP(3)
-    // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125), coalesced store
+    // A = [I, dt I; dt*dqdd_dq, I + dt*dqdd_dv]  (WBM.cpp:68, 122-125): the lower half is the data (RecLayout), coalesced store
     HS_PHASE_L(NT,
-        store_image<NT, 1296, 36>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return (r < 18) ? (((c == r) ? 1.0 : 0.0) + ((c == 18 + r) ? dt : 0.0)) : D.W[WR0 + (r - 18) * 36 + c]; });
+        store_image<NT, 648, 18>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return D.W[WR0 + r * 36 + c]; });     /* rows 18..35 of A (the upper rows are [I, dt I]) */
         store_image<NT, 432, 36>(P.C + kk * P.rs, tid, [&](int e, int, int) { return D.stC()[e]; });
-        store_image<NT, 432, 36>(P.B + kk * P.rs, tid, [&](int, int r, int j) { return (r < 18) ? 0.0 : D.stB()[(r - 18) + 18 * j]; });
+        store_image<NT, 216, 18>(P.B + kk * P.rs, tid, [&](int e, int, int) { return D.stB()[e]; });     /* rows 18..35 of B (the upper rows are zero) */
         store_image<NT, 144, 12>(P.D + kk * P.rs, tid, [&](int e, int, int) { return D.stD()[e]; });)
     LQ_STAMP(4)
     // ---------------- cost partials

@@ -177,6 +177,7 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, dou
         return 0;
     }
     if (!src) { memset(dst, 0, sz * nb * 8); return 0; }
+    if (wb_structured(h->ph[phase], field)) { for (size_t r = 0; r < (size_t)nb * count; r++) wb_expand_ab(field, h->ph[phase].dt, src + ((size_t)b0 * count + r) * stride, dst + r * elems); return 0; }
     for (size_t r = 0; r < (size_t)nb * count; r++) memcpy(dst + r * elems, src + ((size_t)b0 * count + r) * stride, (size_t)elems * 8);
     return 0;
 }
