@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slo
     }
 }
 
-template <class R, int SET>
-__device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, const OptDev& opt, ProbState* st, double fixed_reg, int regularized,
+template <class R, int SET, class LDS>
+__device__ __forceinline__ void sweep_body(LDS& S, const PhaseDev* ph, int nph, const OptDev& opt, ProbState* st, double fixed_reg, int regularized,
                                            int do_linear, double lin_eps, int* success_out) {
     const int b = blockIdx.x;
     bool success = false;
@@ -260,6 +260,9 @@ __device__ __forceinline__ void sweep_body(typename SweepLdsOf<R>::type& S, cons
 // One sweep kernel per (scalar type, model set): the 24-row factor of the kinodynamic model needs twice the registers of the 12-row ones,
 // and a kernel that carries both spills in every instantiation (whole-body kernel alone: 230 registers, no scratch, 150 SGPR spills;
 // with the 24/24/0 phases in the same kernel: 256 + scratch, 850 SGPR spills).
+#ifndef SW_WB_WAVES
+#define SW_WB_WAVES 3      // waves per SIMD the whole-body sweep is compiled for: 50 KB of LDS per workgroup -> three workgroups per CU (168 registers)
+#endif
 #define SWEEP_KERNEL(NAME, R_, SET_, LDS_, MINW_) \
 __global__ void __launch_bounds__(SW_NT, MINW_) NAME(const PhaseDev* ph_, int nph, OptDev opt, ProbState* st, int mask, double fixed_reg, int regularized, \
                                                      int do_linear, double lin_eps, int* success_out, unsigned long long* units, int nknots) { \
@@ -277,13 +280,13 @@ __global__ void __launch_bounds__(SW_NT, MINW_) NAME(const PhaseDev* ph_, int np
     __syncthreads(); \
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; } \
 }
-SWEEP_KERNEL(k_sweep, double, SW_SET_WB, SweepLds, SW_MINB)           // whole-body (+ SRB tail) phases
-SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLds, SW_MINB)      // kinodynamic 24/24/0 phases, fp64
+SWEEP_KERNEL(k_sweep, double, SW_SET_WB, SweepLds, SW_WB_WAVES)           // whole-body (+ SRB tail) phases
+SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)      // kinodynamic 24/24/0 phases, fp64
 // fp32 handles (hsddp_create_ex): fp32 LQ records, every product of the Riccati step on v_mfma_f32_16x16x4_f32, an LDS block a third the size
 // (kinodynamic 24/24/0 and single-rigid-body phases only: SinglePhase.cpp:565-567, HKDModel.h:33-61)
 SWEEP_KERNEL(k_sweep32, float, SW_SET_HKD, SweepLds32, 4)
-LINEAR_KERNEL(k_linear, double, SW_SET_WB, SweepLds, SW_MINB)
-LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLds, SW_MINB)
+LINEAR_KERNEL(k_linear, double, SW_SET_WB, SweepLds, SW_WB_WAVES)
+LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)
 LINEAR_KERNEL(k_linear32, float, SW_SET_HKD, SweepLds32, 4)
 
 // receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase / hsddp_reconfigure): one workgroup per (problem, destination knot).

@@ -46,31 +46,39 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 
 // LDS working set of one Riccati step for a model with dims (N, M, PY); leading dimensions padded to rows + 1
 // (conflict-free column access).  All three instantiations are views over the same raw LDS block (SweepLds).
-// R: the scalar the sweep computes in - double, or float for the fp32 handles of hsddp_create_ex (fp32 LQ records, v_mfma_f32_16x16x4_f32)
+// R: the scalar the sweep computes in - double, or float for the fp32 handles of hsddp_create_ex (fp32 LQ records, v_mfma_f32_16x16x4_f32).
+// Two views over one raw LDS block.  Riccati step: H (value-function Hessian of knot k+1, then Qxx, then H of knot k, all in place), the stored
+// rows of A and B, HA / HB, Qux, C, D, lyy, Quu; K shares storage with lC and the (negated) inverse of Quu with lD (dead before they are born).
+// lxx never sits in LDS: it goes from the prefetch registers straight into H (see riccati_phase).  Whole body: 6 264 doubles = 50.1 KB, three
+// workgroups per CU.
 template <int N, int M, int PY, class R = double> struct SweepLdsT {
     static constexpr int LDN = N + 1, LDM = (M > PY ? M : PY) + 1, PYd = PY > 0 ? PY : 1;
     static constexpr int AR = rec_arows(N), LDA = AR + 1, A0 = N - AR;      // A, B: the stored (lower AR) rows, i.e. rows A0.. of the full matrices
-    R H[LDN * N], A[LDA * N], HA[LDN * N], Qxx[LDN * N];
+    R H[LDN * N], A[LDA * N], HA[LDN * N];
     R B[LDA * M], HB[LDN * M];
-    R Qux[LDM * N], K[LDM * N], C[PY > 0 ? LDM * N : 1], lC[PY > 0 ? LDM * N : 1];
-    R D[PY > 0 ? LDM * M : 1], lD[PY > 0 ? LDM * M : 1], lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M], LQ[LDM * M];
-    R G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N], rdQ[M];
+    R Qux[LDM * N];
+    union { R K[LDM * N]; R lC[PY > 0 ? LDM * N : 1]; };
+    R C[PY > 0 ? LDM * N : 1], D[PY > 0 ? LDM * M : 1];
+    union { R LQ[LDM * M]; R lD[PY > 0 ? LDM * M : 1]; };
+    R lyy[PY > 0 ? LDM * PY : 1], Quu[LDM * M];
+    R G[N], Gn[N], Qx[N], Qu[M], dU[M], ly[PYd], def[N];
+};
+// Linear rollout: two sets of (stored rows of A, lxx, stored rows of B, K, luu, vectors) alternate between knots, dense leading dimensions
+template <int N, int M, int PY, class R = double> struct LinLdsT {
+    static constexpr int AR = rec_arows(N), A0 = N - AR;
+    R A[2][AR * N], Q[2][N * N], B[2][AR * M], K[2][M * N], U[2][M * M], v[2][256];     // v: lx | lu at 64 | dU at 128 | Defect[k+1] at 192
     R dx[N], dxn[N], du[M];
-    R red[SW_NT];
 };
 // what survives a phase boundary: value-function gradient / state deviation handed to the neighbouring phase, dV, status
 struct SweepCtl { double dV1, dV2, xfer[SW_N]; unsigned long long t_last; int ok; };
-using SweepWB = SweepLdsT<36, 12, 12>;
-using SweepSRB = SweepLdsT<12, 12, 0>;
-using SweepHKD = SweepLdsT<24, 24, 0>;
-struct SweepLds { double raw[sizeof(SweepWB) / sizeof(double)]; SweepCtl c; };
-static_assert(sizeof(SweepHKD) <= sizeof(SweepWB) && sizeof(SweepSRB) <= sizeof(SweepWB), "the whole-body view is the largest");
-// the fp32 handles hold kinodynamic / single-rigid-body phases only: their LDS block is a third of the fp64 one (six workgroups per CU)
-using SweepHKD32 = SweepLdsT<24, 24, 0, float>;
-struct SweepLds32 { float raw[sizeof(SweepHKD32) / sizeof(float)]; SweepCtl c; };
-static_assert(sizeof(SweepLdsT<12, 12, 0, float>) <= sizeof(SweepHKD32), "the kinodynamic view is the largest fp32 one");
-template <class R> struct SweepLdsOf { using type = SweepLds; };
-template <> struct SweepLdsOf<float> { using type = SweepLds32; };
+constexpr size_t sw_max(size_t a, size_t b) { return a > b ? a : b; }
+template <class R> constexpr size_t sweep_bytes_wb() { return sw_max(sw_max(sizeof(SweepLdsT<36, 12, 12, R>), sizeof(LinLdsT<36, 12, 12, R>)), sw_max(sizeof(SweepLdsT<12, 12, 0, R>), sizeof(LinLdsT<12, 12, 0, R>))); }
+template <class R> constexpr size_t sweep_bytes_hkd() { return sw_max(sw_max(sizeof(SweepLdsT<24, 24, 0, R>), sizeof(LinLdsT<24, 24, 0, R>)), sw_max(sizeof(SweepLdsT<12, 12, 0, R>), sizeof(LinLdsT<12, 12, 0, R>))); }
+// one raw block per (scalar type, model set); every view of a set fits its block
+template <class R, int SET> struct SweepLdsRaw { R raw[(SET == 0 ? sweep_bytes_wb<R>() : sweep_bytes_hkd<R>()) / sizeof(R)]; SweepCtl c; };
+using SweepLds = SweepLdsRaw<double, 0>;       // whole-body + SRB phases, fp64
+using SweepLdsHkd = SweepLdsRaw<double, 1>;    // kinodynamic + SRB phases, fp64
+using SweepLds32 = SweepLdsRaw<float, 1>;      // kinodynamic + SRB phases of the fp32 handles
 
 #define CM(M, i, j, ld) (M)[(i) + (ld) * (j)]
 
@@ -257,15 +265,20 @@ template <int NT, class TD, class TS> HD void st_mat(int tid, TD* dst, const TS*
 
 // ---- prefetch of one knot's record (backward sweep): RL::rounds rounds of 256 elements, each inside ONE sub-array,
 //      plus one round for the vectors [lx(N) lu(M) ly(PY) Defect[k+1](N)]
+// lxx (rounds rA .. rA + rQ - 1) travels on its own: it is added to Qxx straight from the registers AFTER the products (SW_RICCATI_LXX), so the
+// Riccati step needs no LDS buffer for it; its next fetch is issued right there.
 #define SW_RICCATI_FETCH(kk_, k_) { \
     const HS_GLOBAL R* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
-    _Pragma("unroll") for (int r = 0; r < RL::rounds; r++) PRE(r) = rec_[NT * r];     /* one base pointer, constant offsets */ \
+    _Pragma("unroll") for (int r = 0; r < RL::rounds; r++) if (r < RL::rA || r >= RL::rA + RL::rQ) PRE(r) = rec_[NT * r];     /* one base pointer, constant offsets */ \
     PRE(RL::rounds) = (tid < N + M + PY) ? rec_[RL::oLx] : (tid < 2 * N + M + PY) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - M - PY] : R(0.0); }
+#define SW_RICCATI_FETCH_LXX(kk_) { \
+    const HS_GLOBAL R* rec_ = grec + (kk_) * (size_t)RL::size + tid; \
+    _Pragma("unroll") for (int r = RL::rA; r < RL::rA + RL::rQ; r++) PRE(r) = rec_[NT * r]; }
+#define SW_RICCATI_LXX() { \
+    _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) { const int e = tid + NT * r; if (e < N * N) S.H[(e % N) + LDN * (e / N)] += PRE(RL::rA + r); } }
 #define SW_RICCATI_COMMIT() { \
     constexpr int PYd = PY > 0 ? PY : 1; \
-    constexpr int AR = RL::AR; constexpr int LDA = AR + 1; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < AR * N) S.A[(e % AR) + LDA * (e / AR)] = PRE(r); } \
-    _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) { const int e = tid + NT * r; if (e < N * N) S.Qxx[(e % N) + LDN * (e / N)] = PRE(RL::rA + r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < AR * M) S.B[(e % AR) + LDA * (e / AR)] = PRE(RL::rA + RL::rQ + r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rC; r++) { const int e = tid + NT * r; if (e < PY * N) S.C[(e % PYd) + LDM * (e / PYd)] = PRE(RL::rA + RL::rQ + RL::rB + r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rD; r++) { const int e = tid + NT * r; if (e < PY * M) S.D[(e % PYd) + LDM * (e / PYd)] = PRE(RL::rA + RL::rQ + RL::rB + RL::rC + r); } \
@@ -315,7 +328,7 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
         // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
-        if (t < t1) { td[q] = MTileT<R>{S.Qxx, LDN, S.Qxx, LDN, 16 * bi, 16 * bj, N, N, S.A, LDA, S.HA + A0, LDN, AR, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg;     // regularisation on Qxx as well: quirk x
+        if (t < t1) { td[q] = MTileT<R>{S.H, LDN, nullptr, 0, 16 * bi, 16 * bj, N, N, S.A, LDA, S.HA + A0, LDN, AR, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg;     // into the H block (dead since phase 1); regularisation on Qxx as well: quirk x
                       if (A0 > 0) { td[q].T = S.HA; td[q].ldt = LDN; td[q].tmode = 2; td[q].tsplit = A0; td[q].tscale = dt; } }
         else if (t < t2) td[q] = MTileT<R>{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDA, S.HA + A0, LDN, AR, true, S.D, LDM, S.lC, LDM, PY};
         else { td[q] = MTileT<R>{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDA, S.HB + A0, LDN, AR, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
@@ -333,7 +346,7 @@ HD void sweep_tiles3(SweepLdsT<N, M, PY, R>& S, int lane) {
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         const int t = W + 4 * q;
-        td[q] = MTileT<R>{S.H, LDN, S.Qxx, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};
+        td[q] = MTileT<R>{S.H, LDN, S.H, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};     // in place: H holds Qxx
     }
     mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0, R>(lane, td);
 }
@@ -354,11 +367,12 @@ HD void sweep_tilesK(SweepLdsT<N, M, PY, R>& S, int lane) {
 }
 
 // One phase of the backward sweep for problem b. On entry S.G/S.H hold (Gprime, Hprime) (already through Px^T).
-template <int NT, int N, int M, int PY, class R>
-HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R reg) {
+template <int NT, int N, int M, int PY, class R, class LDS>
+HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
     constexpr int LDN = ST::LDN, LDM = ST::LDM, AR = ST::AR, LDA = ST::LDA, A0 = ST::A0;
+    static_assert(sizeof(ST) <= sizeof(SS.raw), "the view fits the raw LDS block of its model set");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16;   // 16x16 MFMA tiles per dimension
     const int h = P.h; const R dtR = (R)P.dt;
@@ -371,7 +385,7 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
     HS_PHASE(NT, { const int i = tid % N, j0 = tid / N; if (j0 < NT / N) for (int j = j0; j < N; j += NT / N) CM(S.H, i, j, LDN) += P.Phixx[(size_t)b * N * N + i + N * j]; }
              if (tid < N) { const R g = SWC.xfer[tid] + P.Phix[(size_t)b * N + tid]; S.G[tid] = g; gG[((size_t)b * (h + 1) + h) * N + tid] = g; }
              if (tid == 0) { SWC.ok = 1; }
-             SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1))
+             SW_RICCATI_FETCH((size_t)b * h + (h - 1), h - 1) SW_RICCATI_FETCH_LXX((size_t)b * h + (h - 1)))
     for (int k = h - 1; k >= 0; k--) {
         const size_t kk = (size_t)b * h + k;
         SW_STAMP0()
@@ -386,7 +400,7 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
             if (tid < N) { R s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
         })
         SW_STAMP(1)
-        // phase 2: Qxx += A^T HA + C^T lC (TN x TN) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
+        // phase 2: Qxx - lxx = A^T HA + C^T lC (TN x TN, into the H block) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
@@ -412,15 +426,15 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
                    st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
         SW_STAMP(3)
         // wave 0: Eigen's pivoted LDLT of (Quu - 1e-9 I), positivity test, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:366-375);
-        // meanwhile the other waves symmetrise Qxx (next phase).  Scratch: the HA block (dead since phase 2) and the reduction buffer.
-        ldlt_inverse_w<M, LDM, R>(S.Quu, R(-1e-9), S.LQ, S.HA, reinterpret_cast<int*>(S.red), &SWC.ok);
+        // meanwhile the other waves symmetrise Qxx (next phase).  Scratch: the HA and HB blocks (dead since phase 2).
+        ldlt_inverse_w<M, LDM, R>(S.Quu, R(-1e-9), S.LQ, S.HA, reinterpret_cast<int*>(S.HB), &SWC.ok);
         SW_STAMP(4)
         HS_PHASE_L(NT,
             if (tid >= 64) for (int e = tid - 64; e < N * N; e += NT - 64) {
                 const int i = e % N, j = e / N;
                 if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
-                    const R s = (i / 16 == j / 16) ? (CM(S.Qxx, i, j, LDN) + CM(S.Qxx, j, i, LDN)) / 2 : CM(S.Qxx, i, j, LDN);
-                    CM(S.Qxx, i, j, LDN) = s; CM(S.Qxx, j, i, LDN) = s;
+                    const R s = (i / 16 == j / 16) ? (CM(S.H, i, j, LDN) + CM(S.H, j, i, LDN)) / 2 : CM(S.H, i, j, LDN);
+                    CM(S.H, i, j, LDN) = s; CM(S.H, j, i, LDN) = s;
                 }
             })
         SW_STAMP(5)
@@ -431,7 +445,10 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
             { const int w = tid >> 6, lane = tid & 63;
               switch (w) { case 0: sweep_tilesK<0, N, M, PY, R>(S, lane); break; case 1: sweep_tilesK<1, N, M, PY, R>(S, lane); break;
                            case 2: sweep_tilesK<2, N, M, PY, R>(S, lane); break; default: sweep_tilesK<3, N, M, PY, R>(S, lane); } }
-            if (tid >= NT - M) { const int i = tid - (NT - M); R s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; })
+            if (tid >= NT - M) { const int i = tid - (NT - M); R s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; }
+            // lxx joins Qxx here, from the registers it was prefetched into (symmetric by construction; the symmetrisation of SinglePhase.cpp:376
+            // has acted on the products): Qxx = lxx + A^T H A + C^T lyy C + reg I is complete before the next phase reads it
+            SW_RICCATI_LXX() if (k > 0) SW_RICCATI_FETCH_LXX(kk - 1))
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
@@ -455,8 +472,8 @@ HD bool riccati_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b
 // full multi-phase backward sweep of problem b (phases may differ in dimension: WB 36/12/12, HKD 24/24/0, SRB 12/12/0);
 // returns success, writes dV into S.c.dV1/dV2.  H of the phase being processed sits at the start of the raw block with
 // ld n+1 in every view; the gradient G crosses phase boundaries through S.c.xfer.
-template <int NT, class R, int SET>
-HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R reg) {
+template <int NT, class R, int SET, class LDS>
+HD bool riccati_sweep(LDS& S, const PhaseDev* ph, int nph, int b, R reg) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; })
     for (int i = nph - 1; i >= 0; i--) {
         const PhaseDev& P = ph[i];
@@ -504,29 +521,28 @@ HD bool riccati_sweep(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int n
     PRE(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu) = (tid < N + M) ? rec_[RL::oLx] : (tid < N + 2 * M) ? (R)gdU[(kk_) * M + tid - N - M] \
             : (tid < 2 * N + 2 * M) ? (R)gDefect[((size_t)b * (h + 1) + (k_) + 1) * N + tid - N - 2 * M] : R(0.0); }
 #define SW_LIN_COMMIT(p_) { \
-    R* A_ = (p_) ? S.H : S.A; R* Q_ = (p_) ? S.HA : S.Qxx; R* B_ = (p_) ? S.HB : S.B; R* K_ = (p_) ? S.Qux : S.K; R* U_ = (p_) ? S.LQ : S.Quu; \
-    R* v_base = (p_) ? S.red : S.Qx; (void)v_base; \
+    R* A_ = S.A[p_]; R* Q_ = S.Q[p_]; R* B_ = S.B[p_]; R* K_ = S.K[p_]; R* U_ = S.U[p_]; R* v_ = S.v[p_]; \
     _Pragma("unroll") for (int r = 0; r < RL::rA; r++) { const int e = tid + NT * r; if (e < AR * N) A_[e] = PRE(r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rQ; r++) { const int e = tid + NT * r; if (e < N * N) Q_[e] = PRE(RL::rA + r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rB; r++) { const int e = tid + NT * r; if (e < AR * M) B_[e] = PRE(RL::rA + RL::rQ + r); } \
     _Pragma("unroll") for (int r = 0; r < rK; r++) { const int e = tid + NT * r; if (e < N * M) K_[e] = PRE(RL::rA + RL::rQ + RL::rB + r); } \
     _Pragma("unroll") for (int r = 0; r < RL::rLuu; r++) { const int e = tid + NT * r; if (e < M * M) U_[e] = PRE(RL::rA + RL::rQ + RL::rB + rK + r); } \
-    { const R v_ = PRE(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu); \
-      if (tid < N) ((p_) ? S.red : S.Qx)[tid] = v_; else if (tid < N + M) ((p_) ? S.red + 64 : S.Qu)[tid - N] = v_; \
-      else if (tid < N + 2 * M) ((p_) ? S.red + 128 : S.dU)[tid - N - M] = v_; else if (tid < 2 * N + 2 * M) ((p_) ? S.red + 192 : S.def)[tid - N - 2 * M] = v_; } }
+    { const R w_ = PRE(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu); \
+      if (tid < N) v_[tid] = w_; else if (tid < N + M) v_[64 + tid - N] = w_; \
+      else if (tid < N + 2 * M) v_[128 + tid - N - M] = w_; else if (tid < 2 * N + 2 * M) v_[192 + tid - N - 2 * M] = w_; } }
 
 // one phase of the linear rollout; on entry S.c.xfer holds dx_init (Px * dX_end of the previous phase, or 0), on exit dX_end.
 // Two LDS sets (A, lxx, B, K, luu and the vectors) alternate between knots, so a knot costs two barriers: du = eps dU + K dx, then
 // dx+ = A dx + B du + eps defect together with the commit of the next knot's record into the other set.  The contributions to
 // dV_1 / dV_2 stay in registers (one partial sum per lane) and are added up once per phase.
-template <int NT, int N, int M, int PY, class R>
-HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b, R eps) {
-    using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
+template <int NT, int N, int M, int PY, class R, class LDS>
+HD void linear_phase(LDS& SS, const PhaseDev& P, int b, R eps) {
+    using RL = RecLayout<N, M, PY>; using ST = LinLdsT<N, M, PY, R>;
     constexpr int rK = rec_rnd(M * N) / 256, AR = ST::AR, A0 = ST::A0;
-    static_assert(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT, "prefetch registers / lane maps");
-    static_assert(sizeof(ST::A) / sizeof(R) >= (size_t)AR * N && sizeof(ST::B) / sizeof(R) >= (size_t)AR * M, "dense copies of the stored rows fit the padded buffers");
+    static_assert(RL::rA + RL::rQ + RL::rB + rK + RL::rLuu + 1 <= SW_PRE && 2 * N + 2 * M <= NT && 4 * N <= 192 && 4 * M <= NT && 192 + M <= NT && N <= 64 && M <= 64, "prefetch registers / lane maps");
     const R dtR = (R)P.dt;
     static_assert(offsetof(ST, dx) >= 2 * NT * sizeof(R), "the partial-sum scratch must not reach dx");
+    static_assert(sizeof(ST) <= sizeof(SS.raw), "the view fits the raw LDS block of its model set");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
     const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX;   // read once (see riccati_phase)
@@ -548,8 +564,8 @@ HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b,
     for (int k = 0; k < h; k++) {
         const size_t kk = (size_t)b * h + k;
         const int p = k & 1;
-        const R* A_ = p ? S.H : S.A; const R* Q_ = p ? S.HA : S.Qxx; const R* B_ = p ? S.HB : S.B; const R* K_ = p ? S.Qux : S.K; const R* U_ = p ? S.LQ : S.Quu;
-        const R* Qx_ = p ? S.red : S.Qx; const R* Qu_ = p ? S.red + 64 : S.Qu; const R* dU_ = p ? S.red + 128 : S.dU; const R* def_ = p ? S.red + 192 : S.def;
+        const R* A_ = S.A[p]; const R* Q_ = S.Q[p]; const R* B_ = S.B[p]; const R* K_ = S.K[p]; const R* U_ = S.U[p];
+        const R* Qx_ = S.v[p]; const R* Qu_ = S.v[p] + 64; const R* dU_ = S.v[p] + 128; const R* def_ = S.v[p] + 192;
         const R* dxc = p ? S.dxn : S.dx; R* dxw = p ? S.dx : S.dxn;
         // du = eps dU + K dx : row o by the four lanes of quad o
         HS_PHASE_L(NT, SW_QUAD_ROWS(M, {
@@ -578,9 +594,9 @@ HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b,
     }
     const R* dxe = (h & 1) ? S.dxn : S.dx;
     // terminal: dV_1 += Phix . dx ; dV_2 += dx^T Phixx dx ; then the per-lane partial sums of the whole phase
-    HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Qxx[e] = P.Phixx[(size_t)b * N * N + e];)
+    HS_PHASE(NT, for (int e = tid; e < N * N; e += NT) S.Q[0][e] = P.Phixx[(size_t)b * N * N + e];)
     HS_PHASE(NT, if (tid % SW_QS == 0 && tid / SW_QS < N) { const int o = tid / SW_QS;      // on the lanes that carry the x-part partial sums
-                     R q = 0; for (int j = 0; j < N; j++) q += CM(S.Qxx, o, j, N) * dxe[j]; ACC2 += dxe[o] * q; ACC1 += P.Phix[(size_t)b * N + o] * dxe[o]; })
+                     R q = 0; for (int j = 0; j < N; j++) q += CM(S.Q[0], o, j, N) * dxe[j]; ACC2 += dxe[o] * q; ACC1 += P.Phix[(size_t)b * N + o] * dxe[o]; })
     R* scr = SS.raw;     // 2 x NT partial sums (the matrices are no longer needed; dx / dxn live beyond the first 2 NT doubles of every view)
     HS_PHASE(NT, scr[tid] = ACC1; scr[NT + tid] = ACC2;)
     HS_PHASE(NT, if (tid == 0) { R a1 = 0, a2 = 0; for (int j = 0; j < N; j++) { a1 += scr[SW_QS * j]; a2 += scr[NT + SW_QS * j]; }
@@ -592,8 +608,8 @@ HD void linear_phase(typename SweepLdsOf<R>::type& SS, const PhaseDev& P, int b,
 }
 
 // linear rollout of problem b (eps = 1 in solve).  Returns dV_1, dV_2 in S.c.dV1/dV2.
-template <int NT, class R, int SET>
-HD void linear_rollout(typename SweepLdsOf<R>::type& S, const PhaseDev* ph, int nph, int b, R eps) {
+template <int NT, class R, int SET, class LDS>
+HD void linear_rollout(LDS& S, const PhaseDev* ph, int nph, int b, R eps) {
     HS_PHASE(NT, if (tid == 0) { S.c.dV1 = 0.0; S.c.dV2 = 0.0; } if (tid < SW_N) S.c.xfer[tid] = 0.0;)
     for (int i = 0; i < nph; i++) {
         const PhaseDev& P = ph[i];

@@ -137,23 +137,23 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
     return 0;
 }
 int hsddp_backward_sweep(hsddp_handle_t* h, double reg, int* success) {
-    static SweepLds S; static SweepLds32 S32;
+    static SweepLds S; static SweepLdsHkd SH; static SweepLds32 S32;
     for (int b = 0; b < h->batch; b++) {
         bool ok;
         bool hkd = false; for (auto& P : h->ph) hkd |= P.model == HSDDP_MODEL_HKD;
         if (h->f32) { ok = riccati_sweep<SW_NT, float, SW_SET_HKD>(S32, h->ph.data(), h->nph, b, (float)reg); h->dV1[b] = S32.c.dV1; h->dV2[b] = S32.c.dV2; }
-        else if (hkd) { ok = riccati_sweep<SW_NT, double, SW_SET_HKD>(S, h->ph.data(), h->nph, b, reg); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+        else if (hkd) { ok = riccati_sweep<SW_NT, double, SW_SET_HKD>(SH, h->ph.data(), h->nph, b, reg); h->dV1[b] = SH.c.dV1; h->dV2[b] = SH.c.dV2; }
         else { ok = riccati_sweep<SW_NT, double, SW_SET_WB>(S, h->ph.data(), h->nph, b, reg); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
         if (success) success[b] = ok;
     }
     return 0;
 }
 int hsddp_linear_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t*) {
-    static SweepLds S; static SweepLds32 S32;
+    static SweepLds S; static SweepLdsHkd SH; static SweepLds32 S32;
     for (int b = 0; b < h->batch; b++) {
         bool hkd = false; for (auto& P : h->ph) hkd |= P.model == HSDDP_MODEL_HKD;
         if (h->f32) { linear_rollout<SW_NT, float, SW_SET_HKD>(S32, h->ph.data(), h->nph, b, (float)eps); h->dV1[b] = S32.c.dV1; h->dV2[b] = S32.c.dV2; }
-        else if (hkd) { linear_rollout<SW_NT, double, SW_SET_HKD>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
+        else if (hkd) { linear_rollout<SW_NT, double, SW_SET_HKD>(SH, h->ph.data(), h->nph, b, eps); h->dV1[b] = SH.c.dV1; h->dV2[b] = SH.c.dV2; }
         else { linear_rollout<SW_NT, double, SW_SET_WB>(S, h->ph.data(), h->nph, b, eps); h->dV1[b] = S.c.dV1; h->dV2[b] = S.c.dV2; }
     }
     return 0;

@@ -13,6 +13,7 @@ for step in "$@"; do
     hkd32) timeout -k 10 420 python3 bench.py --hkd f32 --steps 5 --warmup 1 > $OUT/hkd32.json 2> $OUT/hkd32.err; echo "hkd32 rc=$?" | tee -a $OUT/summary.txt; cut -c1-1800 $OUT/hkd32.json; tail -3 $OUT/hkd32.err ;;
     hkd64) timeout -k 10 420 python3 bench.py --hkd f64 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/hkd64.json 2> $OUT/hkd64.err; echo "hkd64 rc=$?" | tee -a $OUT/summary.txt; cut -c1-1800 $OUT/hkd64.json; tail -3 $OUT/hkd64.err ;;
     wpe3) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=3" > $OUT/build_wpe3.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/wpe3.log 2>&1; echo "wpe3 rc=$?" | tee -a $OUT/summary.txt; cat $OUT/wpe3.log ;;
+    sw2) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DSW_WB_WAVES=2" > $OUT/build_sw2.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/sw2.log 2>&1; echo "sw2 rc=$?" | tee -a $OUT/summary.txt; cat $OUT/sw2.log ;;
     micro) timeout -k 10 300 python3 tools/microbench.py > $OUT/micro.log 2>&1; echo "micro rc=$?" | tee -a $OUT/summary.txt; cat $OUT/micro.log ;;
     rollprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DROLL_PROF" > $OUT/build_rollprof.log 2>&1 && ROLL_PROF=1 timeout -k 10 300 python3 tools/microbench.py > $OUT/rollprof.log 2>&1; echo "rollprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/rollprof.log ;;
     swprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DSW_PROF" > $OUT/build_swprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/swprof.log 2>&1; echo "swprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/swprof.log ;;
