@@ -6,6 +6,7 @@
 // With -DHS_HOST_EMU (tests/_emu only: a CPU lane-emulator used to debug kernel logic in a container
 // that has no GPU — never built into or loaded by the product) a phase is a plain loop over ids.
 #pragma once
+#include <cstddef>
 #include <cmath>
 #include <cstdint>
 
@@ -69,8 +70,11 @@ template <int NT> __device__ __forceinline__ void hs_phase_sync_all() { hs_phase
 // same, and the value x must have been computed by this point (pins a dependent chain between two batches of loads)
 #ifdef HS_HOST_EMU
 #define HS_PIN(x)
+#define HS_PIN_S(x)
 #else
 #define HS_PIN(x) asm volatile("" : "+v"(x) :: "memory")
+// a wave-uniform value that must sit in a scalar register here (keeps a select chain over descriptor fields from turning into one branch per field)
+#define HS_PIN_S(x) asm volatile("" : "+s"(x))
 #endif
 
 namespace hs {
@@ -103,6 +107,7 @@ template <class S> HD S mk(double v, bool seed);
 template <> HD double mk<double>(double v, bool) { return v; }
 template <> HD Dual mk<Dual>(double v, bool seed) { return Dual(v, seed ? 1.0 : 0.0); }
 
+HD double hs_fma(double a, double b, double c) { return fma(a, b, c); }
 // 1/sqrt(x): one reciprocal-square-root instead of a square root plus two divisions in every Cholesky column
 #ifdef HS_HOST_EMU
 HD double hs_rsqrt(double x) { return 1.0 / std::sqrt(x); }

@@ -53,6 +53,8 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     if ((wb || hkd) && d.c_grf && P.nc > 0) { P.go_grf = ng; ng += 5 * P.nc; }
     if (srb) { P.n_td = 0; P.has_impact = 0; for (int l = 0; l < 4; l++) P.td[l] = 0; }
     P.ng = ng; P.nt = (!srb && d.c_touchdown) ? P.n_td : 0; P.slot0 = slot0;
+    { int offs[5], sz[5]; P.nobj = constraint_objects(P, offs, sz); P.obj_off = P.obj_sz = 0;
+      for (int o = 0; o < P.nobj; o++) { P.obj_off |= (unsigned long long)offs[o] << (8 * o); P.obj_sz |= (unsigned long long)sz[o] << (8 * o); } }
     const size_t h1 = P.h + 1, hh = P.h;
     bool ok = true;
     auto up = [&](const double** dst, const double* src, size_t cnt) { void* p = mem.alloc(cnt * 8); if (!p) { ok = false; return; } if (src) mem.upload(p, src, cnt * 8); *dst = (const double*)p; };

@@ -43,6 +43,7 @@ struct PhaseDev {
     int ng, go_torque, go_joint, go_height, go_grf, go_jspeed;   // path-constraint count and group offsets (-1: absent)
     int nt;                                           // terminal constraints (touchdown feet)
     int slot0;                                        // first global slot of this phase (slots = h+1 per phase)
+    int nobj; unsigned long long obj_off, obj_sz;     // constraint objects in the order the reference adds their ReB cost (constraint_objects): first constraint / count of object o in bits [8o, 8o+8)
     // reference arrays shared by the batch: (h+1) x width
     const HS_GLOBAL double *xr, *ur, *yr, *foot_pos, *foot_vel, *body_pos;
     const HS_GLOBAL int* ref_contact;
@@ -84,7 +85,7 @@ HDH int constraint_group(const PhaseDev& P, int c) {
     return 3;
 }
 // constraint objects of a phase in the order the reference adds them (one `l += dt * ReB_cost` each, SinglePhase.cpp:394-402)
-HD int constraint_objects(const PhaseDev& P, int* offs, int* sz) {
+HDH int constraint_objects(const PhaseDev& P, int* offs, int* sz) {
     int n = 0;
     if (P.go_torque >= 0) { offs[n] = P.go_torque; sz[n++] = 24; }
     if (P.go_jspeed >= 0) { offs[n] = P.go_jspeed; sz[n++] = 24; }

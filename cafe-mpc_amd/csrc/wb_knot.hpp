@@ -229,7 +229,7 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
 // A per-lane index into a small descriptor array would be a VECTOR load from the descriptor in the middle of a knot (an exposed
 // round trip for the single wave); the elements are fetched as scalars instead and picked by selects.
 struct Feet4 { int f0, f1, f2, f3; HD int operator[](int i) const { return i == 0 ? f0 : i == 1 ? f1 : i == 2 ? f2 : f3; } };
-HD Feet4 feet_of(PhaseC& P) { return Feet4{P.feet[0], P.feet[1], P.feet[2], P.feet[3]}; }
+HD Feet4 feet_of(PhaseC& P) { int f0 = P.feet[0], f1 = P.feet[1], f2 = P.feet[2], f3 = P.feet[3]; HS_PIN_S(f0); HS_PIN_S(f1); HS_PIN_S(f2); HS_PIN_S(f3); return Feet4{f0, f1, f2, f3}; }     // pinned: the compiler would otherwise turn the selects back into ONE indexed vector load
 template <class T> HD double pick3(const T& w, int a) { const double w0 = w[0], w1 = w[1], w2 = w[2]; return a == 0 ? w0 : a == 1 ? w1 : w2; }
 
 // compact active Jacobian + drift, PADDED to 12 rows (rows >= 3*nc are zero) so that every later loop has a
@@ -450,6 +450,37 @@ HD double wb_constraint(PhaseC& P, const WbCore& L, int c) {
     return fy + P.mu * fz;
 }
 
+// the same value by selects instead of one divergent region per constraint family (a single wave pays every region's LDS round trip):
+//   g = fma(a, v1, t2)   torque / speed / joint / height: a = +-1, v1 the state or control entry, t2 the bound;  GRF: a = mu (1 for the
+//   normal force), v1 = fz, t2 = +-fx / +-fy (0) — the same roundings as the expressions of wb_constraint
+HD double wb_constraint_sel(PhaseC& P, const WbCore& L, int c) {
+    const double* w = reinterpret_cast<const double*>(&L);
+    constexpr int OX = offsetof(WbCore, x) / 8, OU = offsetof(WbCore, u) / 8, OG = offsetof(WbCore, grf) / 8;
+    const int it = c - P.go_torque, is = c - P.go_jspeed, ij = c - P.go_joint;
+    const bool bt = P.go_torque >= 0 && it >= 0 && it < 24, bs = P.go_jspeed >= 0 && is >= 0 && is < 24, bj = P.go_joint >= 0 && ij >= 0 && ij < 24;
+    const bool bh = P.go_height >= 0 && c == P.go_height, lin = bt || bs || bj || bh;
+    const int i = bt ? it : bs ? is : ij, lo = i < 12 ? i : i - 12;           // entry inside a 24-block: lower-bound half / upper-bound half
+    const bool up = i >= 12;
+    const int a3 = lo % 3;
+    const double cj = up ? pick3(P.joint_ub, a3) : -pick3(P.joint_lb, a3);
+    const double c0 = bt ? P.torque_limit : bs ? (up ? P.jspeed_ub : -P.jspeed_lb) : bj ? cj : -P.h_min;
+    const double sg = bt ? (up ? 1.0 : -1.0) : (bh || !up) ? 1.0 : -1.0;
+    const int i1l = bt ? OU + lo : bs ? OX + 24 + lo : bj ? OX + 6 + lo : OX + 2;
+    const int ig = lin ? 0 : c - P.go_grf, ga = ig / 5, gr = ig - 5 * ga, f = feet_of(P)[ga];
+    const int i1 = lin ? i1l : OG + 3 * f + 2, i2 = lin ? i1l : OG + 3 * f + (gr >= 3 ? 1 : 0);
+    const double v1 = w[i1], v2 = w[i2];
+    const double a = lin ? sg : (gr == 0 ? 1.0 : P.mu);
+    const double t2 = lin ? c0 : (gr == 0 ? 0.0 : ((gr == 1 || gr == 3) ? -v2 : v2));
+    return hs_fma(a, v1, t2);
+}
+// reb_barrier with ONE logarithm: -log(g) above delta, the quadratic extension minus log(delta) below (ConstraintsBase.h:238-245)
+HD double reb_barrier1(double g, double delta) {
+    const bool above = g > delta;
+    const double lg = log(above ? g : delta);
+    const double t = (g - 2 * delta) / delta;
+    return above ? -lg : .5 * (t * t - 1) - lg;
+}
+
 struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // per (problem, slot) partials
 
 // Copy-out of a CNT-element image whose element e = r + ROWS*c is produced by f(e, r, c) (LDS reads / constants): fully unrolled, every
@@ -490,7 +521,8 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         double va = 0, vb = 0, vc = 0, vd = 0, ve = 0;
         if (tid < 36) { va = P.Xbar[kx + tid]; vb = P.dX[kx + tid]; vc = P.xr[(size_t)k * 36 + tid]; if (!ss) { vd = P.Xbar[kx + 36 + tid]; ve = P.dX[kx + 36 + tid]; } }
         else if (tid < 48) { const int i = tid - 36; vc = P.ur[(size_t)k * 12 + i]; vd = P.Ubar[ku + i]; ve = P.dU[ku + i]; }
-        else if (tid < 60) vc = P.foot_vel[(size_t)k * 12 + tid - 48];
+        else if (tid < 60) { const int i = tid - 48; vc = P.foot_vel[(size_t)k * 12 + i]; vd = P.foot_pos[(size_t)k * 12 + i]; ve = P.body_pos[(size_t)k * 3 + i % 3]; }
+        else if (tid < 64) vc = (double)P.ref_contact[(size_t)k * 4 + tid - 60];
         const double vw = (tid < 36) ? P.q[tid] : (tid < 48) ? P.r[tid - 36] : 0.0;
         double kr[7], er[2], dr[2];
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
@@ -501,7 +533,8 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
             L.xb[tid] = xb; L.x[tid] = x; if (wr) P.X[kx + tid] = x;
             L.tmp[tid] = vc; L.red[tid] = ss ? 0.0 : vd + eps * ve;
         } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
-        else if (tid < 60) L.tmp[tid] = vc;
+        else if (tid < 60) { L.tmp[tid] = vc; L.red[tid] = vd - ve; }     // reference foot position relative to the body (foot costs below)
+        else if (tid < 64) L.red[tid] = vc;                               // reference contact flags
         if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;
         _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = kr[q]; }
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
@@ -543,9 +576,8 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         const int i = tid - 36; if (wr) P.Y[kk * 12 + i] = L.grf[i];
         const double du = L.u[i] - L.tmp[tid]; S[tid] = du * L.wq[36 + i] * du;
     } else if (tid < 52) {     // foot costs of foot f: place regulariser (stance), swing position, swing velocity (MHPCCost.cpp:4-245)
-        const int f = tid - 48; const int rc = P.ref_contact[(size_t)k * 4 + f];
-        const double* fp = P.foot_pos + (size_t)k * 12; const double* bp = P.body_pos + (size_t)k * 3;
-        const double d0 = (L.fpos[3 * f] - L.x[0]) - (fp[3 * f] - bp[0]), d1 = (L.fpos[3 * f + 1] - L.x[1]) - (fp[3 * f + 1] - bp[1]), d2 = (L.fpos[3 * f + 2] - L.x[2]) - (fp[3 * f + 2] - bp[2]);
+        const int f = tid - 48; const int rc = (int)L.red[60 + f];
+        const double d0 = (L.fpos[3 * f] - L.x[0]) - L.red[48 + 3 * f], d1 = (L.fpos[3 * f + 1] - L.x[1]) - L.red[48 + 3 * f + 1], d2 = (L.fpos[3 * f + 2] - L.x[2]) - L.red[48 + 3 * f + 2];
         double l2 = 0, l3 = 0, l4 = 0;
         if (rc > 0 && P.w_foot_reg[0] >= 0) l2 = 0.5 * (d0 * P.w_foot_reg[0] * d0 + d1 * P.w_foot_reg[1] * d1 + d2 * P.w_foot_reg[2] * d2) * P.dt;
         if (rc == 0 && P.w_swing_pos[0] >= 0) l3 = 0.5 * (d0 * P.w_swing_pos[0] * d0 + d1 * P.w_swing_pos[1] * d1 + d2 * P.w_swing_pos[2] * d2) * P.dt;
@@ -555,43 +587,44 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         }
         S[48 + f] = l2; S[52 + f] = l3; S[56 + f] = l4;
     }
-    double gmin = 0.0;     // this lane's share of min(0, min_c g_c); the 64 partial minima are folded by one lane below (a minimum does not depend on the order)
+    double gmin = 0.0;     // this lane's share of min(0, min_c g_c); the partial minima are folded below (a minimum does not depend on the order)
     for (int c = tid; c < P.ng; c += NT) {
-        const double g = wb_constraint(P, L, c), e = L.gval()[c], dl = L.bar()[c];
-        if (wr) P.g[kk * P.ng + c] = g; L.gval()[c] = g; L.bar()[c] = e * reb_barrier(g, dl); gmin = fmin(gmin, g);
+        const double g = wb_constraint_sel(P, L, c), e = L.gval()[c], dl = L.bar()[c];
+        if (wr) P.g[kk * P.ng + c] = g;
+        L.bar()[c] = e * reb_barrier1(g, dl); gmin = fmin(gmin, g);
     }
     if (tid < 64) S[200 + tid] = gmin;)
     RL_STAMP(4)
-    HS_PHASE(NT, if (tid == 0) {          // running cost in the reference's order of additions
-        double lq = 0, lr = 0;
-        for (int i = 0; i < 36; i++) lq += S[i];
-        for (int i = 0; i < 12; i++) lr += S[36 + i];
-        double l = 0.5 * lq; l += 0.5 * lr; l *= P.dt;
-        double l2 = 0, l3 = 0, l4 = 0;
-        for (int f = 0; f < 4; f++) { l2 += S[48 + f]; l3 += S[52 + f]; l4 += S[56 + f]; }
-        l += l2; l += l3; l += l4;
-        if (wr) P.lbase[kk] = l; S[140] = l;
-    } else if (tid >= 8 && tid < 13) {    // ReB_cost of constraint object tid-8 (SinglePhase.cpp:394-402)
-        int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); const int gI = tid - 8;
-        // same order of additions as before, but a fixed trip count (an object has at most 24 constraints): the LDS reads are batched
-        // instead of one exposed round trip per term
-        double c = 0; const int n_ = gI < nobj ? sz[gI] : 0, o_ = gI < nobj ? offs[gI] : 0;
-        _Pragma("unroll") for (int i = 0; i < 24; i++) { const double v = L.bar()[o_ + (i < n_ ? i : 0)]; if (i < n_) c += v; }
-        S[141 + gI] = c;
-    } else if (tid == 16) {
-        double ming = 0; _Pragma("unroll") for (int c = 0; c < 64; c++) ming = fmin(ming, S[200 + c]);
-        so.ming[slot] = ming; so.maxh[slot] = 0.0;
-    } else if (tid == 32) {
-        double dsq = 0; for (int i = 0; i < 36; i++) dsq += S[64 + i];
-        so.dsq[slot] = dsq;
-    } else if (tid == 48) {
-        double nsq = 0; for (int i = 0; i < 36; i++) nsq += S[100 + i];
-        if (sqrt(nsq) > 1e6 || !(nsq == nsq)) fail_flag[b] = 1;   // SinglePhase.cpp:205
+    // every sum of the knot in ONE instruction stream: lane 0 the state terms, 1 the control terms, 2..4 the foot terms, 5 the squared defect,
+    // 6 the squared norm of the simulated state, 7..11 the ReB cost of constraint object lane-7 (SinglePhase.cpp:394-402) — each lane adds its
+    // own run of consecutive LDS entries in the reference's order (fixed trip count; entries past the run's end are other data of the knot,
+    // in bounds, and add 0); (first entry, length) of a run come out of packed constants by shifts, not out of a branch per role.  Lanes
+    // 16..19 fold a quarter of the partial minima each.
+    HS_PHASE(NT, {
+        const double* w = reinterpret_cast<const double*>(&L);
+        constexpr int OS = offsetof(WbCore, JX) / 8, OBAR = offsetof(WbCore, GG) / 8 + 288 + MAXG;
+        constexpr unsigned long long RUN_OFF = 0ull | 36ull << 8 | 48ull << 16 | 52ull << 24 | 56ull << 32 | 64ull << 40 | 100ull << 48,
+                                     RUN_LEN = 36ull | 12ull << 8 | 4ull << 16 | 4ull << 24 | 4ull << 32 | 36ull << 40 | 36ull << 48;
+        unsigned long long po = P.obj_off, pl = P.obj_sz; HS_PIN_S(po); HS_PIN_S(pl);
+        const bool fixed = tid < 7; const int sh = 8 * (fixed ? tid : (tid < 12 ? tid - 7 : 7));
+        const int off = (fixed ? OS : OBAR) + (int)(((fixed ? RUN_OFF : po) >> sh) & 255), n = (int)(((fixed ? RUN_LEN : pl) >> sh) & 255);
+        double sum = 0;
+        _Pragma("unroll") for (int i = 0; i < 36; i++) { const double v = w[off + i]; sum += (i < n) ? v : 0.0; }
+        double sm = 0; const int mo = OS + 200 + 16 * (tid & 3);
+        _Pragma("unroll") for (int i = 0; i < 16; i++) sm = fmin(sm, w[mo + i]);
+        if (tid < 12) S[140 + tid] = sum;
+        if (tid >= 16 && tid < 20) S[180 + tid] = sm;
+        if (tid == 5) so.dsq[slot] = sum;
+        if (tid == 6 && (sqrt(sum) > 1e6 || !(sum == sum))) fail_flag[b] = 1;   // SinglePhase.cpp:205
     })
-    HS_PHASE(NT, if (tid == 0) {
-        double l = S[140];
-        if (reb_active) { int offs[5], sz[5]; const int nobj = constraint_objects(P, offs, sz); for (int gI = 0; gI < nobj; gI++) l += P.dt * S[141 + gI]; }
+    HS_PHASE(NT, if (tid == 0) {          // running cost in the reference's order of additions
+        double l = 0.5 * S[140]; l += 0.5 * S[141]; l *= P.dt;
+        l += S[142]; l += S[143]; l += S[144];
+        if (wr) P.lbase[kk] = l;
+        if (reb_active) { _Pragma("unroll") for (int gI = 0; gI < 5; gI++) if (gI < P.nobj) l += P.dt * S[147 + gI]; }
         if (wr) P.l[kk] = l; so.cost[slot] = l;
+    } else if (tid == 16) {
+        so.ming[slot] = fmin(fmin(S[196], S[197]), fmin(S[198], S[199])); so.maxh[slot] = 0.0;
     })
     RL_STAMP(5)
 }
