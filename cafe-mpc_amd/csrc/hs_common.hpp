@@ -80,6 +80,9 @@ template <int NT> __device__ __forceinline__ void hs_phase_sync_all() { hs_phase
 namespace hs {
 
 constexpr int WAVE = 64;
+
+// Sparsity pattern of a triangular factor.  NZ::nz(i, k), k < i: whether L(i,k) can be non-zero (a compile-time pattern; updates with a structurally zero multiplier are not issued).
+struct DenseNZ { static constexpr bool nz(int, int) { return true; } };
 constexpr double GRAV = 9.81;
 
 // forward-mode scalar: value + one tangent
@@ -128,7 +131,7 @@ HD double hs_readlane(double v, int src) {
 // of the matrix in the REGISTERS of lane i: the pivot and the column being eliminated travel by lane broadcast, so a
 // column costs a dependent chain of a few instructions instead of an LDS round trip plus a workgroup barrier.
 // Must be called with all 64 lanes active.  Lo may alias A.
-template <int N, int LD>
+template <int N, int LD, class NZ = DenseNZ>
 HD void chol_r(const double* A, int sr, int sk, double* Lo, double* rd, double diag_add, int tid, int* ok = nullptr) {   // A(i,k) = A[i*sr + k*sk]
     const int row = tid < N ? tid : N - 1;          // idle lanes mirror the last row (never written back)
     double a[N];
@@ -144,7 +147,7 @@ HD void chol_r(const double* A, int sr, int sk, double* Lo, double* rd, double d
         a[j] = lij;
         rown = (tid == j) ? r : rown;
         _Pragma("unroll")
-        for (int k = j + 1; k < N; k++) a[k] -= lij * hs_readlane(lij, k);
+        for (int k = j + 1; k < N; k++) if (NZ::nz(k, j)) a[k] -= lij * hs_readlane(lij, k);
     }
     if (tid < N) {
         rd[tid] = rown;

@@ -98,12 +98,12 @@ HD void chol_s(const double* A, double* Lo, double* rd, double diag_add) {
         })
     }
 }
-template <int NT, int N, int LD>
+template <int NT, int N, int LD, class NZ = DenseNZ>
 HD void chol_f(const double* A, double* Lo, double* rd, double diag_add) {
 #ifdef HS_HOST_EMU
-    chol_s<NT, N, LD>(A, Lo, rd, diag_add);
+    chol_s<NT, N, LD>(A, Lo, rd, diag_add);      // (structural zeros come out as exact zeros of the dense recurrence)
 #else
-    HS_PHASE(NT, chol_r<N, LD>(A, LD, 1, Lo, rd, diag_add, tid);)
+    HS_PHASE(NT, chol_r<N, LD, NZ>(A, LD, 1, Lo, rd, diag_add, tid);)
 #endif
 }
 // in-place factorisation of a 12x12 matrix by ONE wave (tid = lane): registers + lane broadcasts on the GPU, plain loops in the emulator
@@ -119,31 +119,39 @@ HD void chol_f(const double* A, double* Lo, double* rd, double diag_add) {
 // x = L^-1 b (forward) in registers; b/x are private arrays.  The factor row of step i+1 is fetched from LDS (a broadcast read per
 // entry) into registers BEFORE the dependent multiply-add chain of row i runs: a single wave has no other wave to hide the LDS
 // latency behind, so the loads are batched and pipelined by hand (the fence keeps the compiler from sinking them back).
-template <int N, int LD> HD void fwd_s(const double* Lo, const double* rd, double* x) {
+template <int N, int LD, class NZ = DenseNZ> HD void fwd_s(const double* Lo, const double* rd, double* x) {
     double lr[2][N];
     _Pragma("unroll")
     for (int i = 0; i < N; i++) {
-        if (i + 1 < N) { _Pragma("unroll") for (int k = 0; k <= i; k++) lr[(i + 1) & 1][k] = Lo[(i + 1) * LD + k]; }
+        if (i + 1 < N) { _Pragma("unroll") for (int k = 0; k <= i; k++) if (NZ::nz(i + 1, k)) lr[(i + 1) & 1][k] = Lo[(i + 1) * LD + k]; }
         HS_CBAR();
         double s = x[i];
         _Pragma("unroll")
-        for (int k = 0; k < i; k++) s -= lr[i & 1][k] * x[k];
+        for (int k = 0; k < i; k++) if (NZ::nz(i, k)) s -= lr[i & 1][k] * x[k];
         x[i] = s * rd[i];
     }
 }
 // x = L^-T b (backward) in registers
-template <int N, int LD> HD void bwd_s(const double* Lo, const double* rd, double* x) {
+template <int N, int LD, class NZ = DenseNZ> HD void bwd_s(const double* Lo, const double* rd, double* x) {
     double lr[2][N];
     _Pragma("unroll")
     for (int i = N - 1; i >= 0; i--) {
-        if (i > 0) { _Pragma("unroll") for (int k = i; k < N; k++) lr[(i - 1) & 1][k] = Lo[k * LD + (i - 1)]; }
+        if (i > 0) { _Pragma("unroll") for (int k = i; k < N; k++) if (NZ::nz(k, i - 1)) lr[(i - 1) & 1][k] = Lo[k * LD + (i - 1)]; }
         HS_CBAR();
         double s = x[i];
         _Pragma("unroll")
-        for (int k = i + 1; k < N; k++) s -= lr[i & 1][k] * x[k];
+        for (int k = i + 1; k < N; k++) if (NZ::nz(k, i)) s -= lr[i & 1][k] * x[k];
         x[i] = s * rd[i];
     }
 }
+
+// The mass matrix is factored LEGS FIRST: position i < 12 of the permuted order is leg joint 6 + i, positions 12..17 are the floating base.
+// A leg joint only couples with its own leg and the base, so the factor has no entries between different legs (and none fills in): 99
+// instead of 153 multiplier entries in the factorisation and in every triangular solve.  Vectors between a forward and a backward solve
+// (and the rows of X = L^-1 Jc^T) live in the permuted order; wb_pi / wb_pj translate at the loads and stores.
+HD constexpr int wb_pi(int i) { return i < 12 ? i + 6 : i - 12; }     // permuted position -> joint
+HD constexpr int wb_pj(int j) { return j < 6 ? j + 12 : j - 6; }      // joint -> permuted position
+struct WbNZ { static constexpr bool nz(int i, int k) { return i >= 12 || (k / 3 == i / 3); } };
 
 HD LaneCfg lane_cfg(const ModelDev& md, bool kin, double mscale, double grav, double fscale, double vscale, double ascale, int aunit, int tq, int tv) {
     LaneCfg c;
@@ -158,7 +166,7 @@ struct PSink {   // value pass: lanes 0..17 -> column `lane` of M and of all foo
     HD void base(const V3<double>& f, const V3<double>& n) const {   // per-leg task: partial base wrench (GG is free while the terms are formed)
         double* p = L->GG + 6 * task; p[0] = f.x; p[1] = f.y; p[2] = f.z; p[3] = n.x; p[4] = n.y; p[5] = n.z;
     }
-    HD void tau(int i, double v) const { if (lane < 18) L->M[i * 18 + lane] = v; else L->h[i] = v; }
+    HD void tau(int i, double v) const { if (lane < 18) L->M[wb_pj(i) * 18 + wb_pj(lane)] = v; else L->h[i] = v; }     // M in the legs-first order
     HD void foot(int f, const V3<double>& p, const V3<double>& v, const V3<double>& a) const {
         if (lane < 18) { L->Jall[(3 * f) * 18 + lane] = a.x; L->Jall[(3 * f + 1) * 18 + lane] = a.y; L->Jall[(3 * f + 2) * 18 + lane] = a.z; }
         else {
@@ -206,7 +214,7 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
         wb_pass<double>(c, L.x, L.x + 18, L.acc, L.cs, L.sn, L.fext, sk);
         if (tid < 12) {    // a leg-joint column is zero on the other legs' rows and feet
             for (int f = 0; f < 4; f++) if (f != leg) {
-                for (int r = 0; r < 3; r++) { L.M[(6 + 3 * f + r) * 18 + col] = 0.0; L.Jall[(3 * f + r) * 18 + col] = 0.0; }
+                for (int r = 0; r < 3; r++) { L.M[(3 * f + r) * 18 + wb_pj(col)] = 0.0; L.Jall[(3 * f + r) * 18 + col] = 0.0; }
             }
         }
     })
@@ -239,7 +247,7 @@ HD void wb_select(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) 
     HS_PHASE(NT,
         for (int e = tid; e < 216; e += NT) {
             const int a = e / 18, j = e % 18; const bool act = a < 3 * nc;
-            L.Jc()[e] = act ? L.Jall[(3 * feet[act ? a / 3 : 0] + a % 3) * 18 + j] : 0.0;
+            L.Jc()[e] = act ? L.Jall[(3 * feet[act ? a / 3 : 0] + a % 3) * 18 + wb_pi(j)] : 0.0;      // columns in the legs-first order
         }
         if (tid < 12) {
             const bool act = tid < 3 * nc;
@@ -267,20 +275,20 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
     LQ_STAMP(7)
-    chol_f<NT, 18, 18>(L.M, L.M, L.rdM, 0.0);
+    chol_f<NT, 18, 18, WbNZ>(L.M, L.M, L.rdM, 0.0);
     LQ_STAMP(8)
     HS_PHASE(NT, if (tid < 12) {             // X[:, tid] = L^-1 Jc[tid, :]^T
         double x[18];
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) x[i] = L.Jc()[tid * 18 + i];
-        fwd_s<18, 18>(L.M, L.rdM, x);
+        fwd_s<18, 18, WbNZ>(L.M, L.rdM, x);
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) L.Xm()[i * 12 + tid] = x[i];
     } else if (tid == 63) {                  // y = L^-1 (tau - h)  (mode 0) ; 0 (mode 1)
         double y[18];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) y[i] = (mode == 0) ? (L.tau[i] - L.h[i]) : 0.0;
-        fwd_s<18, 18>(L.M, L.rdM, y);
+        for (int i = 0; i < 18; i++) y[i] = (mode == 0) ? (L.tau[wb_pi(i)] - L.h[wb_pi(i)]) : 0.0;
+        fwd_s<18, 18, WbNZ>(L.M, L.rdM, y);
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) L.a0[i] = y[i];
     })
@@ -288,7 +296,7 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
         if (tid >= 48 && tid < 60) {
             const int a = tid - 48; double s = 0;
             if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.a0[i]; }
-            else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.x[18 + i]; }
+            else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.x[18 + wb_pi(i)]; }
             L.rhs[a] = (a < m) ? (-s - L.gam[a]) : 0.0;
         })
     LQ_STAMP(9)
@@ -303,9 +311,9 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
         double z[18];
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) { double s = L.a0[i]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[i * 12 + a] * lam[a]; z[i] = s; }
-        bwd_s<18, 18>(L.M, L.rdM, z);
+        bwd_s<18, 18, WbNZ>(L.M, L.rdM, z);
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) L.qdd[i] = z[i] + ((mode == 1) ? L.x[18 + i] : 0.0);
+        for (int i = 0; i < 18; i++) L.qdd[wb_pi(i)] = z[i] + ((mode == 1) ? L.x[18 + wb_pi(i)] : 0.0);
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
     })
@@ -324,7 +332,7 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
         double z = L.a0[i18];
         _Pragma("unroll") for (int a = 0; a < 12; a++) z += xr[a] * hs_readlane(v, a);
         _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
-        if (tid < 18) L.qdd[tid] = z + ((mode == 1) ? L.x[18 + tid] : 0.0);
+        if (tid < 18) L.qdd[wb_pi(tid)] = z + ((mode == 1) ? L.x[18 + wb_pi(tid)] : 0.0);
         if (tid < 12) { L.lam[tid] = v; if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = v; }
     })
 #endif
@@ -336,7 +344,7 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
 // every lane solves its own right-hand side in registers; factors are read from LDS as broadcasts.
 // in: top[18] (or y directly if top_is_y), bot[12] (entries >= m zero) ; out: top <- upper part, bot <- nu
 HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bot, bool top_is_y) {
-    if (!top_is_y) fwd_s<18, 18>(L.M, L.rdM, top);
+    if (!top_is_y) fwd_s<18, 18, WbNZ>(L.M, L.rdM, top);
     _Pragma("unroll")
     for (int a = 0; a < 12; a++) {
         double s = -bot[a];
@@ -352,7 +360,7 @@ HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bo
         for (int a = 0; a < 12; a++) s -= L.JX[216 + i * 12 + a] * bot[a];
         top[i] = s;
     }
-    bwd_s<18, 18>(L.M, L.rdM, top);
+    bwd_s<18, 18, WbNZ>(L.M, L.rdM, top);
 }
 // Schur factor for the derivative columns: Pinocchio's computeKKTContactDynamicMatrixInverse runs with damping 0 (WBM.cpp:467), unlike
 // the forward solve (1e-12, WBM.cpp:411): G = X^T X is factored once more without the damping, into LDS that survives the tangent pass
@@ -896,7 +904,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         const int d = tid;
         double top[18], bot[12];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0)) : ((i == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF
+        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[wb_pi(i) * WT + d] + ((d < 18) ? D.W[wb_pi(i) * WT + 36 + d] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) {
             bot[a] = 0.0;
@@ -910,14 +918,14 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         wb_kkt_column(L, D, top, bot, false);
         if (d < 36) {
             _Pragma("unroll")
-            for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = -top[i] * dt + ((d == 18 + i) ? 1.0 : 0.0);     // rows 18..35 of A
+            for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = -top[i] * dt + ((d == 18 + wb_pi(i)) ? 1.0 : 0.0);     // rows 18..35 of A
             _Pragma("unroll")
             for (int a = 0; a < 12; a++) D.stC()[a + 12 * d] = 0.0;
             for (int a = 0; a < m; a++) D.stC()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = bot[a];
         } else {
             const int j = d - 36;
             _Pragma("unroll")
-            for (int i = 0; i < 18; i++) D.stB()[i + 18 * j] = top[i] * dt;
+            for (int i = 0; i < 18; i++) D.stB()[wb_pi(i) + 18 * j] = top[i] * dt;
             _Pragma("unroll")
             for (int a = 0; a < 12; a++) D.stD()[a + 12 * j] = 0.0;
             for (int a = 0; a < m; a++) D.stD()[(3 * P.feet[a / 3] + a % 3) + 12 * j] = -bot[a];
@@ -1010,7 +1018,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         const int d = tid;
         double top[18], bot[12];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[i * WT + d] + ((d < 18) ? D.W[i * WT + 36 + d] : 0.0)) : ((i == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF
+        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[wb_pi(i) * WT + d] + ((d < 18) ? D.W[wb_pi(i) * WT + 36 + d] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) {
             bot[a] = 0.0;
@@ -1024,14 +1032,14 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         wb_kkt_column(L, D, top, bot, false);
         if (d < 36) {
             _Pragma("unroll")
-            for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = -top[i] * dt + ((d == 18 + i) ? 1.0 : 0.0);     // rows 18..35 of A
+            for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = -top[i] * dt + ((d == 18 + wb_pi(i)) ? 1.0 : 0.0);     // rows 18..35 of A
             _Pragma("unroll")
             for (int a = 0; a < 12; a++) D.stC()[a + 12 * d] = 0.0;
             for (int a = 0; a < m; a++) D.stC()[(3 * P.feet[a / 3] + a % 3) + 12 * d] = bot[a];
         } else {
             const int j = d - 36;
             _Pragma("unroll")
-            for (int i = 0; i < 18; i++) D.stB()[i + 18 * j] = top[i] * dt;
+            for (int i = 0; i < 18; i++) D.stB()[wb_pi(i) + 18 * j] = top[i] * dt;
             _Pragma("unroll")
             for (int a = 0; a < 12; a++) D.stD()[a + 12 * j] = 0.0;
             for (int a = 0; a < m; a++) D.stD()[(3 * P.feet[a / 3] + a % 3) + 12 * j] = -bot[a];
@@ -1158,15 +1166,15 @@ HD void wb_lq_terminal(WbLqLds& S, PhaseC& P, PhaseC* Pn, const ModelDev& md, in
         double top[18], bot[12];
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) {
-            if (d < 18) top[i] = D.W[i * WT + d];
-            else { const int j = d - 18; top[i] = (i < j) ? L.M[j * 18 + i] : (i == j) ? 1.0 / L.rdM[j] : 0.0; }
+            if (d < 18) top[i] = D.W[wb_pi(i) * WT + d];
+            else { const int j = wb_pj(d - 18); top[i] = (i < j) ? L.M[j * 18 + i] : (i == j) ? 1.0 / L.rdM[j] : 0.0; }     // M e_(d-18) in the permuted order = L L^T e_j
         }
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) bot[a] = (d < 18 && a < m) ? L.dvel()[(3 * tdfeet[a / 3] + a % 3) * 18 + d] : 0.0;
         wb_kkt_column(L, D, top, bot, d >= 18);
         // results into rows 18..35 of W (rows 0..17 still hold the tangents other lanes read)
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) D.W[WR0 + i * 36 + d] = (d < 18) ? -top[i] : top[i];
+        for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = (d < 18) ? -top[i] : top[i];
     })
     HS_PHASE(NT, for (int e = tid; e < nn * 36; e += NT) {
         const int r = e % nn, c = e / nn;

@@ -445,10 +445,11 @@ def test_single_shooting_solve_parity(hip_lib, oracle_lib, oracle_ld_lib, which)
         assert s_.backward_sweep(0.0).all()
     pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6, exact=sx)
     assert np.abs(sg.field(0, "DEFECT")).max() == 0.0
-    for s_ in (so, sg):
+    for s_ in (so, sg, sx):
         s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
-    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1")
-    so.close(); sg.close()
+    # a single-shooting rollout through gains of 4e4 amplifies the rounding of the states: the long-double run bounds what fp64 can agree on
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1", exact=sx)
+    so.close(); sg.close(); sx.close()
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
     sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
     so.solve(opt); sg.solve(opt); sx.solve(opt)
