@@ -249,6 +249,7 @@ HD void wb_select(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) 
             const int a = e / 18, j = e % 18; const bool act = a < 3 * nc;
             L.Jc()[e] = act ? L.Jall[(3 * feet[act ? a / 3 : 0] + a % 3) * 18 + wb_pi(j)] : 0.0;      // columns in the legs-first order
         }
+        for (int e = tid; e < 144; e += NT) L.G()[e] = (e % 13 == 0) ? 1.0 : 0.0;     // identity: the padding of the Gram matrix beyond the active block
         if (tid < 12) {
             const bool act = tid < 3 * nc;
             const int f = act ? feet[tid / 3] : 0, r = tid % 3;
@@ -256,15 +257,65 @@ HD void wb_select(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) 
             L.grf[tid] = 0.0;
         })
 }
-// G = X^T X (12x12, padded rows/cols get the identity), 144 entries dealt over the wave ; X = Xm (18x12)
-HD void wb_gram(WbCore& L, int m, int tid, int nt) {
-    for (int e = tid; e < 144; e += nt) {
-        const int a = e / 12, b = e % 12;
+// G = X^T X, the leading NM x NM block of the 12 x 12 matrix (rows / columns >= m keep the identity wb_select put there), dealt over the wave ; X = Xm (18x12)
+template <int NM> HD void wb_gram(WbCore& L, int m, int tid, int nt) {
+    for (int e = tid; e < NM * NM; e += nt) {
+        const int a = e / NM, b = e % NM;
         double s = 0;
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.Xm()[i * 12 + b];
-        L.G()[e] = (b >= m || a >= m) ? ((a == b) ? 1.0 : 0.0) : s;
+        if (a < m && b < m) L.G()[a * 12 + b] = s;
     }
+}
+
+// Second half of the contact solve on the leading NM x NM block of the Gram matrix (NM = 6: at most two feet in contact, half the columns
+// of every phase below): G = X^T X, its factor, lam, qdd.
+template <int NT, int NM>
+HD void wb_kkt_tail(WbCore& L, int m, const Feet4& feet, int mode) {
+    HS_PHASE(NT, wb_gram<NM>(L, m, tid, NT);
+        if (tid >= 48 && tid < 60) {
+            const int a = tid - 48; double s = 0;
+            if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.a0[i]; }
+            else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.x[18 + wb_pi(i)]; }
+            L.rhs[a] = (a < m) ? (-s - L.gam[a]) : 0.0;
+        })
+    LQ_STAMP(9)
+    chol_f<NT, NM, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
+    LQ_STAMP(10)
+#ifdef HS_HOST_EMU
+    HS_PHASE(NT, if (tid == 0) {             // lam = G^-1 rhs ; then z = y + X lam ; back substitution L^T qdd = z
+        double lam[12];
+        _Pragma("unroll")
+        for (int i = 0; i < 12; i++) lam[i] = L.rhs[i];
+        fwd_s<NM, 12>(L.LG(), L.rdG, lam); bwd_s<NM, 12>(L.LG(), L.rdG, lam);
+        double z[18];
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) { double s = L.a0[i]; _Pragma("unroll") for (int a = 0; a < NM; a++) s += L.Xm()[i * 12 + a] * lam[a]; z[i] = s; }
+        bwd_s<18, 18, WbNZ>(L.M, L.rdM, z);
+        _Pragma("unroll")
+        for (int i = 0; i < 18; i++) L.qdd[wb_pi(i)] = z[i] + ((mode == 1) ? L.x[18 + wb_pi(i)] : 0.0);
+        _Pragma("unroll")
+        for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
+    })
+#else
+    // lam = G^-1 rhs ; z = y + X lam ; back substitution L^T qdd = z — across the lanes of the wave: lane i owns entry i, the
+    // entry just finished travels by lane broadcast, the factor entries each lane needs are preloaded from LDS
+    HS_PHASE(NT, {
+        const int i12 = tid < NM ? tid : NM - 1, i18 = tid < 18 ? tid : 17;
+        double lgr[NM], lgc[NM], xr[NM], lmc[18];
+        _Pragma("unroll") for (int k = 0; k < NM; k++) { lgr[k] = L.LG()[i12 * 12 + k]; lgc[k] = L.LG()[k * 12 + i12]; xr[k] = L.Xm()[i18 * 12 + k]; }
+        _Pragma("unroll") for (int k = 0; k < 18; k++) lmc[k] = L.M[k * 18 + i18];
+        const double rg = L.rdG[i12], rm = L.rdM[i18];
+        double v = L.rhs[i12];
+        _Pragma("unroll") for (int k = 0; k < NM; k++) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid > k) ? v - lgr[k] * xk : v); }
+        _Pragma("unroll") for (int k = NM - 1; k >= 0; k--) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid < k) ? v - lgc[k] * xk : v); }
+        double z = L.a0[i18];
+        _Pragma("unroll") for (int a = 0; a < NM; a++) z += xr[a] * hs_readlane(v, a);
+        _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
+        if (tid < 18) L.qdd[wb_pi(tid)] = z + ((mode == 1) ? L.x[18 + wb_pi(tid)] : 0.0);
+        if (tid < 12) { const double lm = tid < NM ? v : 0.0; L.lam[tid] = lm; if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = lm; }
+    })
+#endif
 }
 
 // Contact solve WITHOUT forming M^-1 (rollout): M = L L^T in place, X = L^-1 Jc^T, G = X^T X (+damping),
@@ -292,50 +343,7 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) L.a0[i] = y[i];
     })
-    HS_PHASE(NT, wb_gram(L, m, tid, NT);
-        if (tid >= 48 && tid < 60) {
-            const int a = tid - 48; double s = 0;
-            if (mode == 0) { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Xm()[i * 12 + a] * L.a0[i]; }
-            else { _Pragma("unroll") for (int i = 0; i < 18; i++) s += L.Jc()[a * 18 + i] * L.x[18 + wb_pi(i)]; }
-            L.rhs[a] = (a < m) ? (-s - L.gam[a]) : 0.0;
-        })
-    LQ_STAMP(9)
-    chol_f<NT, 12, 12>(L.G(), L.LG(), L.rdG, (mode == 0) ? 1e-12 : 0.0);
-    LQ_STAMP(10)
-#ifdef HS_HOST_EMU
-    HS_PHASE(NT, if (tid == 0) {             // lam = G^-1 rhs ; then z = y + X lam ; back substitution L^T qdd = z
-        double lam[12];
-        _Pragma("unroll")
-        for (int i = 0; i < 12; i++) lam[i] = L.rhs[i];
-        fwd_s<12, 12>(L.LG(), L.rdG, lam); bwd_s<12, 12>(L.LG(), L.rdG, lam);
-        double z[18];
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) { double s = L.a0[i]; _Pragma("unroll") for (int a = 0; a < 12; a++) s += L.Xm()[i * 12 + a] * lam[a]; z[i] = s; }
-        bwd_s<18, 18, WbNZ>(L.M, L.rdM, z);
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) L.qdd[wb_pi(i)] = z[i] + ((mode == 1) ? L.x[18 + wb_pi(i)] : 0.0);
-        _Pragma("unroll")
-        for (int a = 0; a < 12; a++) { L.lam[a] = lam[a]; if (a < m) L.grf[3 * feet[a / 3] + a % 3] = lam[a]; }
-    })
-#else
-    // lam = G^-1 rhs ; z = y + X lam ; back substitution L^T qdd = z — across the lanes of the wave: lane i owns entry i, the
-    // entry just finished travels by lane broadcast, the factor entries each lane needs are preloaded from LDS
-    HS_PHASE(NT, {
-        const int i12 = tid < 12 ? tid : 11, i18 = tid < 18 ? tid : 17;
-        double lgr[12], lgc[12], xr[12], lmc[18];
-        _Pragma("unroll") for (int k = 0; k < 12; k++) { lgr[k] = L.LG()[i12 * 12 + k]; lgc[k] = L.LG()[k * 12 + i12]; xr[k] = L.Xm()[i18 * 12 + k]; }
-        _Pragma("unroll") for (int k = 0; k < 18; k++) lmc[k] = L.M[k * 18 + i18];
-        const double rg = L.rdG[i12], rm = L.rdM[i18];
-        double v = L.rhs[i12];
-        _Pragma("unroll") for (int k = 0; k < 12; k++) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid > k) ? v - lgr[k] * xk : v); }
-        _Pragma("unroll") for (int k = 11; k >= 0; k--) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid < k) ? v - lgc[k] * xk : v); }
-        double z = L.a0[i18];
-        _Pragma("unroll") for (int a = 0; a < 12; a++) z += xr[a] * hs_readlane(v, a);
-        _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
-        if (tid < 18) L.qdd[wb_pi(tid)] = z + ((mode == 1) ? L.x[18 + wb_pi(tid)] : 0.0);
-        if (tid < 12) { L.lam[tid] = v; if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = v; }
-    })
-#endif
+    if (m <= 6) wb_kkt_tail<NT, 6>(L, m, feet, mode); else wb_kkt_tail<NT, 12>(L, m, feet, mode);      // uniform over the wave
 }
 
 // One column of the KKT-inverse products the LQ approximation needs, WITHOUT forming M^-1 or the KKT inverse (the
@@ -343,23 +351,28 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
 //   [M Jc^T; Jc 0]^-1 [top; bot] = [ L^-T (y - X nu) ; nu ],   y = L^-1 top,  nu = G^-1 (X^T y - bot)
 // every lane solves its own right-hand side in registers; factors are read from LDS as broadcasts.
 // in: top[18] (or y directly if top_is_y), bot[12] (entries >= m zero) ; out: top <- upper part, bot <- nu
-HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bot, bool top_is_y) {
-    if (!top_is_y) fwd_s<18, 18, WbNZ>(L.M, L.rdM, top);
+template <int NM> HD void wb_kkt_column_mid(const WbCore& L, const WbDeriv& D, double* top, double* bot) {
     _Pragma("unroll")
-    for (int a = 0; a < 12; a++) {
+    for (int a = 0; a < NM; a++) {
         double s = -bot[a];
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) s += L.JX[216 + i * 12 + a] * top[i];
         bot[a] = s;
     }
-    fwd_s<12, 12>(D.LGs, D.rdGs, bot); bwd_s<12, 12>(D.LGs, D.rdGs, bot);
+    fwd_s<NM, 12>(D.LGs, D.rdGs, bot); bwd_s<NM, 12>(D.LGs, D.rdGs, bot);
     _Pragma("unroll")
     for (int i = 0; i < 18; i++) {
         double s = top[i];
         _Pragma("unroll")
-        for (int a = 0; a < 12; a++) s -= L.JX[216 + i * 12 + a] * bot[a];
+        for (int a = 0; a < NM; a++) s -= L.JX[216 + i * 12 + a] * bot[a];
         top[i] = s;
     }
+}
+// m = 3 nc (uniform over the wave): with at most two feet in contact the constraint part runs on the leading 6 x 6 block (entries of bot
+// beyond it are zero on entry and stay untouched)
+HD void wb_kkt_column(const WbCore& L, const WbDeriv& D, double* top, double* bot, bool top_is_y, int m) {
+    if (!top_is_y) fwd_s<18, 18, WbNZ>(L.M, L.rdM, top);
+    if (m <= 6) wb_kkt_column_mid<6>(L, D, top, bot); else wb_kkt_column_mid<12>(L, D, top, bot);
     bwd_s<18, 18, WbNZ>(L.M, L.rdM, top);
 }
 // Schur factor for the derivative columns: Pinocchio's computeKKTContactDynamicMatrixInverse runs with damping 0 (WBM.cpp:467), unlike
@@ -915,7 +928,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
                 bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
             }
         }
-        wb_kkt_column(L, D, top, bot, false);
+        wb_kkt_column(L, D, top, bot, false, m);
         if (d < 36) {
             _Pragma("unroll")
             for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = -top[i] * dt + ((d == 18 + wb_pi(i)) ? 1.0 : 0.0);     // rows 18..35 of A
@@ -1029,7 +1042,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
                 bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
             }
         }
-        wb_kkt_column(L, D, top, bot, false);
+        wb_kkt_column(L, D, top, bot, false, m);
         if (d < 36) {
             _Pragma("unroll")
             for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = -top[i] * dt + ((d == 18 + wb_pi(i)) ? 1.0 : 0.0);     // rows 18..35 of A
@@ -1171,7 +1184,7 @@ HD void wb_lq_terminal(WbLqLds& S, PhaseC& P, PhaseC* Pn, const ModelDev& md, in
         }
         _Pragma("unroll")
         for (int a = 0; a < 12; a++) bot[a] = (d < 18 && a < m) ? L.dvel()[(3 * tdfeet[a / 3] + a % 3) * 18 + d] : 0.0;
-        wb_kkt_column(L, D, top, bot, d >= 18);
+        wb_kkt_column(L, D, top, bot, d >= 18, m);
         // results into rows 18..35 of W (rows 0..17 still hold the tangents other lanes read)
         _Pragma("unroll")
         for (int i = 0; i < 18; i++) D.W[WR0 + wb_pi(i) * 36 + d] = (d < 18) ? -top[i] : top[i];
