@@ -100,8 +100,12 @@ HD Dual operator*(double a, Dual b) { return Dual(a * b.v, a * b.d); }
 HD Dual operator*(Dual a, double b) { return Dual(a.v * b, a.d * b); }
 HD Dual operator+(Dual a, double b) { return Dual(a.v + b, a.d); }
 HD Dual operator-(Dual a, double b) { return Dual(a.v - b, a.d); }
+#ifdef HS_HOST_EMU
 HD void sincos_(double a, double& s, double& c) { s = sin(a); c = cos(a); }
-HD void sincos_(Dual a, Dual& s, Dual& c) { double sv = sin(a.v), cv = cos(a.v); s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d); }
+#else
+HD void sincos_(double a, double& s, double& c) { sincos(a, &s, &c); }      // one argument reduction for both
+#endif
+HD void sincos_(Dual a, Dual& s, Dual& c) { double sv, cv; sincos_(a.v, sv, cv); s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d); }
 HD double val(double a) { return a; }
 HD double val(Dual a) { return a.v; }
 HD double tang(double) { return 0.0; }
@@ -153,6 +157,59 @@ HD void chol_r(const double* A, int sr, int sk, double* Lo, double* rd, double d
         rd[tid] = rown;
         _Pragma("unroll")
         for (int k = 0; k < N - 1; k++) if (k < tid) Lo[tid * LD + k] = a[k];
+    }
+}
+// value of lane `src` (any lane, per-lane choice) — ds_bpermute moves 32 bits per instruction
+HD double hs_bperm(double v, int src) {
+    const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// Cholesky of the 18 x 18 whole-body mass matrix in the legs-first order (rows 3l..3l+2: leg l, rows 12..17: floating base; no entries
+// between different legs), row i in lane i, in place.  The four 3 x 3 leg blocks do not depend on each other: their three column steps run
+// for all legs AT ONCE (pivot and multipliers travel inside a leg by ds_bpermute), so the dependent chain is 3 + 12 short + 6 column steps
+// instead of 18 full ones; the base rows then take the twelve leg columns in order (the same sequence of multiply-adds per entry as the
+// column-by-column chol_r with the same pattern: bit-identical factor) and the dense 6 x 6 base block follows.  All 64 lanes active.
+HD void chol_wb18(double* M, double* rd, int tid) {
+    const int row = tid < 18 ? tid : 17, leg = row < 12 ? row / 3 : 3, jl = row - 3 * leg;
+    double al[3], a[18];
+    _Pragma("unroll") for (int k = 0; k < 3; k++) al[k] = M[row * 18 + 3 * leg + k];
+    _Pragma("unroll") for (int k = 0; k < 18; k++) a[k] = M[row * 18 + k];
+    double rown = 0.0, rj[3], lj[3];
+    _Pragma("unroll")
+    for (int j = 0; j < 3; j++) {        // leg blocks, column j of every leg
+        const double r = hs_rsqrt(al[j]);                       // meaningful on the pivot lanes (jl == j)
+        rown = (tid < 12 && jl == j) ? r : rown;
+        rj[j] = r;
+        const double lij = al[j] * hs_bperm(r, 3 * leg + j);    // L(row, 3 leg + j), rows below the pivot
+        lj[j] = lij; al[j] = lij;
+        _Pragma("unroll")
+        for (int k = j + 1; k < 3; k++) al[k] -= lij * hs_bperm(lij, 3 * leg + k);
+    }
+    _Pragma("unroll")
+    for (int c = 0; c < 12; c++) {       // base rows (lanes 12..17) against the leg columns, in column order
+        const int l = c / 3, j = c % 3;
+        const double lic = a[c] * hs_readlane(rj[j], c);
+        a[c] = lic;
+        _Pragma("unroll")
+        for (int k = j + 1; k < 3; k++) a[3 * l + k] -= lic * hs_readlane(lj[j], 3 * l + k);
+        _Pragma("unroll")
+        for (int k = 12; k < 18; k++) a[k] -= lic * hs_readlane(lic, k);
+    }
+    _Pragma("unroll")
+    for (int j = 12; j < 18; j++) {      // base block
+        const double r = hs_rsqrt(hs_readlane(a[j], j));
+        const double lij = a[j] * r;
+        a[j] = lij;
+        rown = (tid == j) ? r : rown;
+        _Pragma("unroll")
+        for (int k = j + 1; k < 18; k++) a[k] -= lij * hs_readlane(lij, k);
+    }
+    if (tid < 12) {
+        rd[tid] = rown;
+        _Pragma("unroll") for (int k = 0; k < 2; k++) if (k < jl) M[row * 18 + 3 * leg + k] = al[k];
+    } else if (tid < 18) {
+        rd[tid] = rown;
+        _Pragma("unroll") for (int k = 0; k < 17; k++) if (k < tid) M[tid * 18 + k] = a[k];
     }
 }
 #endif

@@ -194,7 +194,7 @@ struct DSink {   // tangent pass: d tau -> W[i][lane]; kinematic lanes (>=36) al
 };
 
 // trig table of the knot state (18 lanes in parallel)
-template <int NT> HD void wb_trig(WbCore& L) { HS_PHASE(NT, if (tid < 18) { L.cs[tid] = cos(L.x[tid]); L.sn[tid] = sin(L.x[tid]); }) }
+template <int NT> HD void wb_trig(WbCore& L) { HS_PHASE(NT, if (tid < 18) { double sv, cv; sincos_(L.x[tid], sv, cv); L.cs[tid] = cv; L.sn[tid] = sv; }) }
 
 // Phase: M, h, all-foot Jacobians, Jdot*v, foot pos/vel at L.x (psi_dyn), as 40 per-leg TASKS of about a third of a pass each:
 //   lanes 0..11  : column 6+lane (a leg joint) — only its own leg moves, one task
@@ -326,22 +326,28 @@ HD void wb_kkt_direct(WbCore& L, int nc, const Feet4& feet, int mode, double alp
     const int m = 3 * nc;
     wb_select<NT>(L, nc, feet, mode, alpha);
     LQ_STAMP(7)
+#ifdef HS_HOST_EMU
     chol_f<NT, 18, 18, WbNZ>(L.M, L.M, L.rdM, 0.0);
+#else
+    HS_PHASE(NT, chol_wb18(L.M, L.rdM, tid);)
+#endif
     LQ_STAMP(8)
-    HS_PHASE(NT, if (tid < 12) {             // X[:, tid] = L^-1 Jc[tid, :]^T
+    // X[:, tid] = L^-1 Jc[tid, :]^T on lanes 0..11 and y = L^-1 (tau - h) (mode 0; 0 in mode 1) on lane 12: ONE instruction stream, the right-hand
+    // side and the destination picked per lane
+    HS_PHASE(NT, if (tid < 13) {
+        const bool isx = tid < 12;
+        double* w = reinterpret_cast<double*>(&L);
+        constexpr int OXM = offsetof(WbCore, JX) / 8 + 216, OA0 = offsetof(WbCore, a0) / 8;
         double x[18];
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) x[i] = L.Jc()[tid * 18 + i];
+        for (int i = 0; i < 18; i++) {
+            const double jc = L.Jc()[(isx ? tid : 0) * 18 + i], yv = (mode == 0) ? (L.tau[wb_pi(i)] - L.h[wb_pi(i)]) : 0.0;
+            x[i] = isx ? jc : yv;
+        }
         fwd_s<18, 18, WbNZ>(L.M, L.rdM, x);
+        const int o0 = isx ? OXM + tid : OA0, st = isx ? 12 : 1;
         _Pragma("unroll")
-        for (int i = 0; i < 18; i++) L.Xm()[i * 12 + tid] = x[i];
-    } else if (tid == 63) {                  // y = L^-1 (tau - h)  (mode 0) ; 0 (mode 1)
-        double y[18];
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) y[i] = (mode == 0) ? (L.tau[wb_pi(i)] - L.h[wb_pi(i)]) : 0.0;
-        fwd_s<18, 18, WbNZ>(L.M, L.rdM, y);
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) L.a0[i] = y[i];
+        for (int i = 0; i < 18; i++) w[o0 + i * st] = x[i];
     })
     if (m <= 6) wb_kkt_tail<NT, 6>(L, m, feet, mode); else wb_kkt_tail<NT, 12>(L, m, feet, mode);      // uniform over the wave
 }
@@ -884,7 +890,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         }
         if (cached) {
             // trig table straight from the registers (same values wb_trig would read back from LDS), while the cache reads are in flight
-            if (tid < 18) { L.cs[tid] = cos(vx); L.sn[tid] = sin(vx); }
+            if (tid < 18) { double sv, cv; sincos_(vx, sv, cv); L.cs[tid] = cv; L.sn[tid] = sv; }
             _Pragma("unroll") for (int q = 0; q < KC_SIZE / NT; q++) {
                 const int i = q * NT + tid; const double v = r[q];
                 KC_REGION(KC_M, KC_X, L.M) KC_REGION(KC_X, KC_LG, L.Xm()) KC_REGION(KC_LG, KC_RDM, D.LGs) KC_REGION(KC_RDM, KC_RDG, L.rdM)
