@@ -18,6 +18,9 @@
 // wave-level phase: only the first 64 threads of the workgroup run it, ordered by a wave barrier (no s_barrier)
 #define HS_WPHASE(...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
 #define HS_PHASE_L(NT, ...) HS_PHASE(NT, __VA_ARGS__)
+// values a lane keeps in registers from one phase to a later one: the emulator keeps one copy per lane
+#define HS_NLANES(NT) (NT)
+#define HS_LANE(tid) (tid)
 template <int NT> inline void hs_phase_sync_all() {}
 // wave-level phase of wave W of a multi-wave workgroup, tid = lane 0..63 (the emulator runs the waves' phases in program order)
 #define HS_WPHASE_W(W, ...) { for (int tid = 0; tid < 64; ++tid) { __VA_ARGS__ } }
@@ -34,6 +37,9 @@ template <> __device__ __forceinline__ void hs_phase_sync<64>() { asm volatile("
 template <> __device__ __forceinline__ void hs_phase_sync<128>() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the per-knot kernels, one or two waves
 template <int NT> __device__ __forceinline__ void hs_phase_sync_all() { hs_phase_sync<NT>(); }     // a bare workgroup barrier between wave-level phase sequences
 #define HS_PHASE(NT, ...) { { int tid = threadIdx.x; asm volatile("" : "+v"(tid)); __builtin_assume(tid >= 0); if (tid < (NT)) { __VA_ARGS__ } } hs_phase_sync<(NT)>(); }
+// values a lane keeps in registers from one phase to a later one (the emulator keeps one copy per lane)
+#define HS_NLANES(NT) 1
+#define HS_LANE(tid) 0
 // wave-level phase: executed by wave 0 only; a wave runs in lock-step and its LDS operations complete in program
 // order, so the only thing to prevent is compiler motion across the phase boundary.
 // LDS-only phase boundary: raw s_barrier behind an lgkmcnt(0) wait.  __syncthreads() carries a workgroup release fence,

@@ -58,11 +58,15 @@ struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (s
 };
 constexpr int WT = 54, WR0 = 18 * 54;   // T(i,lane) = W[i*WT + lane] ; R(i,d) = W[WR0 + i*36 + d]
 struct WbLqLds { WbCore c; WbDeriv d; };
+// the workgroup whose phases the diagnostic stamps time: one from the middle of a launch (the first workgroups start on cold caches)
+#ifndef HS_PROF_BLOCK
+#define HS_PROF_BLOCK 100007
+#endif
 #if defined(ROLL_PROF_EXTERNAL)
 // (the including file defines RL_STAMP / RL_STAMP0 / KK_STAMP itself: tools/count_instructions.sh places assembler marks there)
 #elif defined(ROLL_PROF) && !defined(HS_HOST_EMU)
-#define RL_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
-#define RL_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
+#define RL_STAMP(i) { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
+#define RL_STAMP0() { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) L.tstamp = clock64(); }
 #else
 #define RL_STAMP(i)
 #define RL_STAMP0()
@@ -72,8 +76,8 @@ __device__ unsigned long long g_lq_prof[16];
 #endif
 #if defined(LQ_PROF_EXTERNAL)
 #elif defined(LQ_PROF) && !defined(HS_HOST_EMU)
-#define LQ_STAMP(i) { if (blockIdx.x == 7 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
-#define LQ_STAMP0() { if (blockIdx.x == 7 && threadIdx.x == 0) L.tstamp = clock64(); }
+#define LQ_STAMP(i) { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
+#define LQ_STAMP0() { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) L.tstamp = clock64(); }
 #else
 #define LQ_STAMP(i)
 #define LQ_STAMP0()
@@ -541,20 +545,28 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12;
     double* Kst = L.Jc();   // 432 doubles: [Jc | Xm] are free until the contact solve
     RL_STAMP0()
-    // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five): the references and the
-    // barrier parameters wait in LDS (tmp / red / the tail of GG) until the phases that use them
+    // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five), the state and the references
+    // FIRST: only they are waited for here (loads return in order); the gain K and the barrier parameters (3.5 KB and the tail of the
+    // queue) stay in registers and are first touched after the dynamics terms, which do not need the control
     const size_t kk = (size_t)b * h + k;
+    struct Late { double kr[7], er[2], dr[2]; } late[HS_NLANES(NT)];
     HS_PHASE(NT,
-        double va = 0, vb = 0, vc = 0, vd = 0, ve = 0;
-        if (tid < 36) { va = P.Xbar[kx + tid]; vb = P.dX[kx + tid]; vc = P.xr[(size_t)k * 36 + tid]; if (!ss) { vd = P.Xbar[kx + 36 + tid]; ve = P.dX[kx + 36 + tid]; } }
-        else if (tid < 48) { const int i = tid - 36; vc = P.ur[(size_t)k * 12 + i]; vd = P.Ubar[ku + i]; ve = P.dU[ku + i]; }
-        else if (tid < 60) { const int i = tid - 48; vc = P.foot_vel[(size_t)k * 12 + i]; vd = P.foot_pos[(size_t)k * 12 + i]; ve = P.body_pos[(size_t)k * 3 + i % 3]; }
-        else if (tid < 64) vc = (double)P.ref_contact[(size_t)k * 4 + tid - 60];
-        const double vw = (tid < 36) ? P.q[tid] : (tid < 48) ? P.r[tid - 36] : 0.0;
-        double kr[7], er[2], dr[2];
-        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
-        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
+        // ONE instruction stream for every lane group (a branch per group would wait for its own loads where the groups merge): the
+        // addresses are picked per lane, idle lanes read a valid dummy
+        const int g = tid < 36 ? 0 : tid < 48 ? 1 : tid < 60 ? 2 : 3, i = tid < 36 ? tid : tid < 48 ? tid - 36 : tid < 60 ? tid - 48 : 0;
+        const double* pa = P.Xbar + kx + (g == 0 ? i : 0); const double* pb = P.dX + kx + (g == 0 ? i : 0);
+        const double* pc = g == 0 ? P.xr + (size_t)k * 36 + i : g == 1 ? P.ur + (size_t)k * 12 + i : P.foot_vel + (size_t)k * 12 + i;
+        const double* pd = g == 0 ? P.Xbar + kx + (ss ? 0 : 36) + i : g == 1 ? P.Ubar + ku + i : P.foot_pos + (size_t)k * 12 + i;
+        const double* pe = g == 0 ? P.dX + kx + (ss ? 0 : 36) + i : g == 1 ? P.dU + ku + i : P.body_pos + (size_t)k * 3 + i % 3;
+        const int rci = P.ref_contact[(size_t)k * 4 + (tid & 3)];
+        double va = *pa, vb = *pb, vc = *pc, vd = *pd, ve = *pe;
+        const double* pw = tid < 36 ? &P.q[tid] : &P.r[tid < 48 ? tid - 36 : 0];      // (one load: two would wait for each other where they merge)
+        const double vw = *pw;
+        Late& lt = late[HS_LANE(tid)];
+        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; lt.kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; lt.er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; lt.dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
         HS_CBAR();
+        if (tid >= 60) vc = (double)rci;
         if (tid < 36) {
             const double xb = va, x = ss ? L.xnext[tid] : xb + eps * vb;
             L.xb[tid] = xb; L.x[tid] = x; if (wr) P.X[kx + tid] = x;
@@ -562,17 +574,20 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
         else if (tid < 60) { L.tmp[tid] = vc; L.red[tid] = vd - ve; }     // reference foot position relative to the body (foot costs below)
         else if (tid < 64) L.red[tid] = vc;                               // reference contact flags
-        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;
-        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = kr[q]; }
-        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
+        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;)
+    RL_STAMP(0)
+    wb_terms<NT>(L, md, true);
+    RL_STAMP(1)
+    HS_PHASE(NT,
+        const Late& lt = late[HS_LANE(tid)];
+        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = lt.kr[q]; }
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = lt.er[q]; L.bar()[c] = lt.dr[q]; } })
     HS_PHASE(NT, if (tid < 12) {
         double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
         double u = L.red[36 + tid] + s;
         L.u[tid] = u; if (wr) P.U[ku + tid] = u; L.tau[6 + tid] = u;
     })
-    RL_STAMP(0)
-    wb_terms<NT>(L, md, true);
-    RL_STAMP(1)
+
     wb_kkt_direct<NT>(L, P.nc, feet_of(P), 0, P.bg_alpha);
     RL_STAMP(2)
     if (wr) {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores
