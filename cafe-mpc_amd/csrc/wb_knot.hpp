@@ -78,6 +78,10 @@ __device__ unsigned long long g_lq_prof[16];
 #elif defined(LQ_PROF) && !defined(HS_HOST_EMU)
 #define LQ_STAMP(i) { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_lq_prof[i], t_ - L.tstamp); L.tstamp = t_; } }
 #define LQ_STAMP0() { if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 0) L.tstamp = clock64(); }
+#elif defined(ROLL_PROF) && !defined(HS_HOST_EMU)
+// rollout profile: the stamps inside the contact solve (7..10) split its share of the knot
+#define LQ_STAMP(i) { if ((i) >= 7 && (i) <= 10) RL_STAMP(i) }
+#define LQ_STAMP0()
 #else
 #define LQ_STAMP(i)
 #define LQ_STAMP0()

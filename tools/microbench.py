@@ -35,7 +35,7 @@ if hasattr(lib, "hsddp_debug_lq_prof") and os.environ.get("ROLL_PROF"):
     lib.hsddp_debug_lq_prof(buf, 1)
     s.hybrid_rollout(1.0, opt)
     lib.hsddp_debug_lq_prof(buf, 0)
-    for i, n in enumerate(["load x, K, u", "terms", "kkt_direct", "integrate/defect", "constraints", "cost (lane 0)"]):
+    for i, n in enumerate(["first reads, x", "terms", "lam, qdd substitution", "cache store", "integrate, constraints", "sums", "", "K store, mat-vec, select", "chol M", "X, y, Gram", "chol G"]):
         print(f"  rollout stamp {i} {n:20s} {buf[i]:10d} cycles")
 elif hasattr(lib, "hsddp_debug_lq_prof"):
     buf = (ctypes.c_ulonglong * 16)()
