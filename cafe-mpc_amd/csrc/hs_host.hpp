@@ -64,7 +64,7 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     auto al = [&](double** dst, size_t cnt) { void* p = mem.alloc(std::max<size_t>(cnt, 1) * 8); if (!p) ok = false; *dst = (double*)p; };
     double** sx[] = {&P.X, &P.Xbar, &P.Xsim, &P.Defect, &P.Defect_bar, &P.dX, &P.G};
     for (auto p : sx) al(p, B * h1 * n);
-    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu};
+    double** su[] = {&P.U, &P.Ubar, &P.dU, &P.Qu, &P.KdX};
     for (auto p : su) al(p, B * hh * m);
     al(&P.Y, B * hh * py);
     double** smn[] = {&P.K, &P.Qux};

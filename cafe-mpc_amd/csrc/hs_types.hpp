@@ -50,6 +50,7 @@ struct PhaseDev {
     // trajectories
     HS_GLOBAL double *X, *Xbar, *Xsim, *Defect, *Defect_bar, *dX, *G;           // (h+1) x n
     HS_GLOBAL double *U, *Ubar, *dU, *Qu;                                        // h x m
+    HS_GLOBAL double *KdX;                                                       // h x m: K[k] dX[k] as the last linear rollout formed it (the whole-body rollout knot takes it instead of re-reading K)
     HS_GLOBAL double *Y;                                                         // h x p
     HS_GLOBAL double *K, *Qux, *Quu;                                             // h x (m*n), h x (m*m)
     HS_GLOBAL double *A, *B, *C, *D;                                             // h x ...

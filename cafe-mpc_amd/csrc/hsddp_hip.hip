@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) k_warm_start(PhaseDev D, PhaseDev S, int 
     }
     if (k < D.h) {
         const bool cs = has_src && ks < S.h; const size_t su = (size_t)b * S.h + ks;
-        for (int i = tid; i < m; i += blockDim.x) { const double v = cs ? S.Ubar[su * m + i] : 0.0; D.Ubar[du * m + i] = v; D.U[du * m + i] = v; D.dU[du * m + i] = 0.0; }
+        for (int i = tid; i < m; i += blockDim.x) { const double v = cs ? S.Ubar[su * m + i] : 0.0; D.Ubar[du * m + i] = v; D.U[du * m + i] = v; D.dU[du * m + i] = 0.0; D.KdX[du * m + i] = 0.0; }
         for (int i = tid; i < m * n; i += blockDim.x) D.K[du * m * n + i] = cs ? S.K[su * m * n + i] : 0.0;
         if (has_src && S.ng == D.ng && S.h > 0) {
             const size_t sg = (size_t)b * S.h + (ks < S.h ? ks : S.h - 1);
@@ -767,7 +767,7 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
         if (!per_problem) HIPCK(dev_replicate(P.Ubar, su * 8, B));
         HIPCK(hipMemcpy(P.U, P.Ubar, B * su * 8, hipMemcpyDeviceToDevice));
     }
-    HIPCK(hipMemset(P.K, 0, B * P.h * P.m * P.n * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
+    HIPCK(hipMemset(P.K, 0, B * P.h * P.m * P.n * 8)); HIPCK(hipMemset(P.dU, 0, B * su * 8)); HIPCK(hipMemset(P.KdX, 0, B * su * 8)); HIPCK(hipMemset(P.dX, 0, B * sx * 8));
     return HSDDP_OK;
 }
 

@@ -545,7 +545,7 @@ HD void linear_phase(LDS& SS, const PhaseDev& P, int b, R eps) {
     static_assert(sizeof(ST) <= sizeof(SS.raw), "the view fits the raw LDS block of its model set");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
     const int h = P.h;
-    const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX;   // read once (see riccati_phase)
+    const auto grec = rec_of<R>(P); const auto gDefect = P.Defect; const auto gK = P.K; const auto gdU = P.dU; const auto gdX = P.dX; const auto gKdX = P.KdX;   // read once (see riccati_phase)
     SW_PRE_DECL
 #ifdef HS_HOST_EMU
     static R acc1_all_[NT], acc2_all_[NT];
@@ -571,7 +571,7 @@ HD void linear_phase(LDS& SS, const PhaseDev& P, int b, R eps) {
         HS_PHASE_L(NT, SW_QUAD_ROWS(M, {
             constexpr int CH = (N + 3) / 4; R s = 0;
             _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int j = part * CH + jj; if (j < N) s += CM(K_, o, j, M) * dxc[j]; }
-            partial = s; }, { S.du[o] = eps * dU_[o] + total; }))
+            partial = s; }, { S.du[o] = eps * dU_[o] + total; gKdX[kk * M + o] = total; }))      // K dX also goes out: the rollout's u = ubar + eps (dU + K dX)
         HS_PHASE_L(NT,
             // dx+ = [A B] [dx; du] + eps defect and q = lxx dx : row o by quad o, a quarter of the N + M (resp. N) terms per lane
             SW_QUAD_ROWS(N, {

@@ -549,16 +549,19 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12;
     double* Kst = L.Jc();   // 432 doubles: [Jc | Xm] are free until the contact solve
     RL_STAMP0()
-    // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five), the state and the references
-    // FIRST: only they are waited for here (loads return in order); the gain K and the barrier parameters (3.5 KB and the tail of the
-    // queue) stay in registers and are first touched after the dynamics terms, which do not need the control
+    // every global read of the knot is issued in this first phase (one exposed HBM latency instead of five).  The control:
+    //   multiple shooting: x - xbar = eps dX, so  u = ubar + eps dU + K (x - xbar) = ubar + eps (dU + K dX)  with K dX as the linear rollout
+    //   left it (P.KdX, 12 values) - the knot does not read the 432 entries of K at all (equal to the reference's expression up
+    //   to the rounding of x - xbar);
+    //   single shooting (ss): x is the simulated state, K (x - xbar) is formed here; K travels in registers past the dynamics terms, which
+    //   do not need the control.
     const size_t kk = (size_t)b * h + k;
-    struct Late { double kr[7], er[2], dr[2]; } late[HS_NLANES(NT)];
+    struct Late { double kr[7]; } late[HS_NLANES(NT)];
     HS_PHASE(NT,
         // ONE instruction stream for every lane group (a branch per group would wait for its own loads where the groups merge): the
         // addresses are picked per lane, idle lanes read a valid dummy
         const int g = tid < 36 ? 0 : tid < 48 ? 1 : tid < 60 ? 2 : 3, i = tid < 36 ? tid : tid < 48 ? tid - 36 : tid < 60 ? tid - 48 : 0;
-        const double* pa = P.Xbar + kx + (g == 0 ? i : 0); const double* pb = P.dX + kx + (g == 0 ? i : 0);
+        const double* pa = g == 0 ? P.Xbar + kx + i : (g == 1 && !ss) ? P.KdX + ku + i : P.Xbar + kx; const double* pb = P.dX + kx + (g == 0 ? i : 0);
         const double* pc = g == 0 ? P.xr + (size_t)k * 36 + i : g == 1 ? P.ur + (size_t)k * 12 + i : P.foot_vel + (size_t)k * 12 + i;
         const double* pd = g == 0 ? P.Xbar + kx + (ss ? 0 : 36) + i : g == 1 ? P.Ubar + ku + i : P.foot_pos + (size_t)k * 12 + i;
         const double* pe = g == 0 ? P.dX + kx + (ss ? 0 : 36) + i : g == 1 ? P.dU + ku + i : P.body_pos + (size_t)k * 3 + i % 3;
@@ -566,32 +569,37 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         double va = *pa, vb = *pb, vc = *pc, vd = *pd, ve = *pe;
         const double* pw = tid < 36 ? &P.q[tid] : &P.r[tid < 48 ? tid - 36 : 0];      // (one load: two would wait for each other where they merge)
         const double vw = *pw;
-        Late& lt = late[HS_LANE(tid)];
-        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; lt.kr[q] = (i < 432) ? P.K[kk * 432 + i] : 0.0; }
-        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; lt.er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; lt.dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
+        double er[2], dr[2];
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
+        if (ss) { Late& lt = late[HS_LANE(tid)]; _Pragma("unroll") for (int q = 0; q < 7; q++) { const int e = q * NT + tid; lt.kr[q] = (e < 432) ? P.K[kk * 432 + e] : 0.0; } }
         HS_CBAR();
         if (tid >= 60) vc = (double)rci;
         if (tid < 36) {
             const double xb = va, x = ss ? L.xnext[tid] : xb + eps * vb;
             L.xb[tid] = xb; L.x[tid] = x; if (wr) P.X[kx + tid] = x;
             L.tmp[tid] = vc; L.red[tid] = ss ? 0.0 : vd + eps * ve;
-        } else if (tid < 48) { L.tmp[tid] = vc; L.red[tid] = vd + eps * ve; }
+        } else if (tid < 48) {
+            L.tmp[tid] = vc;
+            if (ss) L.red[tid] = vd + eps * ve;
+            else { const double u = vd + eps * (ve + va); L.u[i] = u; if (wr) P.U[ku + i] = u; L.tau[6 + i] = u; }
+        }
         else if (tid < 60) { L.tmp[tid] = vc; L.red[tid] = vd - ve; }     // reference foot position relative to the body (foot costs below)
         else if (tid < 64) L.red[tid] = vc;                               // reference contact flags
-        if (tid < 18) { L.acc[tid] = 0.0; L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;)
+        if (tid < 18) { L.acc[tid] = 0.0; if (ss || tid < 6) L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;
+        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
     RL_STAMP(0)
     wb_terms<NT>(L, md, true);
     RL_STAMP(1)
-    HS_PHASE(NT,
-        const Late& lt = late[HS_LANE(tid)];
-        _Pragma("unroll") for (int q = 0; q < 7; q++) { const int i = q * NT + tid; if (i < 432) Kst[i] = lt.kr[q]; }
-        _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = lt.er[q]; L.bar()[c] = lt.dr[q]; } })
-    HS_PHASE(NT, if (tid < 12) {
-        double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
-        double u = L.red[36 + tid] + s;
-        L.u[tid] = u; if (wr) P.U[ku + tid] = u; L.tau[6 + tid] = u;
-    })
-
+    if (ss) {
+        HS_PHASE(NT,
+            const Late& lt = late[HS_LANE(tid)];
+            _Pragma("unroll") for (int q = 0; q < 7; q++) { const int e = q * NT + tid; if (e < 432) Kst[e] = lt.kr[q]; })
+        HS_PHASE(NT, if (tid < 12) {
+            double s = 0; for (int j = 0; j < 36; j++) s += Kst[tid + 12 * j] * (L.x[j] - L.xb[j]);
+            double u = L.red[36 + tid] + s;
+            L.u[tid] = u; if (wr) P.U[ku + tid] = u; L.tau[6 + tid] = u;
+        })
+    }
     wb_kkt_direct<NT>(L, P.nc, feet_of(P), 0, P.bg_alpha);
     RL_STAMP(2)
     if (wr) {   // contact-solve cache for the LQ approximation of this knot (hs_types.hpp KC_*): fire-and-forget stores

@@ -6,12 +6,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4096); ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--hkd", choices=["f32", "f64"], default=None, help="the kinodynamic bound-gait problem (config 5) instead of the whole-body trot")
 a = ap.parse_args()
 pkg = ge.load_package()
-ph = pkg.problems.wb_trot_problem()
-s = pkg.MultiPhaseDDP(ph, batch=a.batch)
-s.set_initial_condition(pkg.problems.wb_ensemble_x0(a.batch, 1))
-opt = pkg.mhpc_ddp_setting()
+if a.hkd:
+    ph = pkg.problems.hkd_bound_problem()
+    s = pkg.MultiPhaseDDP(ph, batch=a.batch, precision=(pkg.PREC_F32 if a.hkd == "f32" else pkg.PREC_F64))
+    s.set_initial_condition(pkg.problems.hkd_ensemble_x0(a.batch, 1, ph))
+    opt = pkg.problems.hkd_ddp_setting()
+else:
+    ph = pkg.problems.wb_trot_problem()
+    s = pkg.MultiPhaseDDP(ph, batch=a.batch)
+    s.set_initial_condition(pkg.problems.wb_ensemble_x0(a.batch, 1))
+    opt = pkg.mhpc_ddp_setting()
 s.hybrid_rollout(0.0, opt); s.update_nominal_trajectory()
 for _ in range(a.reps):
     s.LQ_approximation(opt); s.backward_sweep(0.0); s.linear_rollout(1.0, opt); s.hybrid_rollout(1.0, opt)
