@@ -244,7 +244,9 @@ HD void wb_terms(WbCore& L, const ModelDev& md, bool need_cols) {
 
 // A per-lane index into a small descriptor array would be a VECTOR load from the descriptor in the middle of a knot (an exposed
 // round trip for the single wave); the elements are fetched as scalars instead and picked by selects.
-struct Feet4 { int f0, f1, f2, f3; HD int operator[](int i) const { return i == 0 ? f0 : i == 1 ? f1 : i == 2 ? f2 : f3; } };
+struct Feet4 { int f0, f1, f2, f3; HD int operator[](int i) const { return i == 0 ? f0 : i == 1 ? f1 : i == 2 ? f2 : f3; }
+    // per-LANE slot i (0..3): shifts on one packed scalar - the compiler turns a select chain over the four fields back into branches
+    HD int pick(int i) const { return (((f0 & 3) | (f1 & 3) << 2 | (f2 & 3) << 4 | (f3 & 3) << 6) >> (2 * i)) & 3; } };
 HD Feet4 feet_of(PhaseC& P) { int f0 = P.feet[0], f1 = P.feet[1], f2 = P.feet[2], f3 = P.feet[3]; HS_PIN_S(f0); HS_PIN_S(f1); HS_PIN_S(f2); HS_PIN_S(f3); return Feet4{f0, f1, f2, f3}; }     // pinned: the compiler would otherwise turn the selects back into ONE indexed vector load
 template <class T> HD double pick3(const T& w, int a) { const double w0 = w[0], w1 = w[1], w2 = w[2]; return a == 0 ? w0 : a == 1 ? w1 : w2; }
 
@@ -255,12 +257,12 @@ HD void wb_select(WbCore& L, int nc, const Feet4& feet, int mode, double alpha) 
     HS_PHASE(NT,
         for (int e = tid; e < 216; e += NT) {
             const int a = e / 18, j = e % 18; const bool act = a < 3 * nc;
-            L.Jc()[e] = act ? L.Jall[(3 * feet[act ? a / 3 : 0] + a % 3) * 18 + wb_pi(j)] : 0.0;      // columns in the legs-first order
+            L.Jc()[e] = act ? L.Jall[(3 * feet.pick(act ? a / 3 : 0) + a % 3) * 18 + wb_pi(j)] : 0.0;      // columns in the legs-first order
         }
         for (int e = tid; e < 144; e += NT) L.G()[e] = (e % 13 == 0) ? 1.0 : 0.0;     // identity: the padding of the Gram matrix beyond the active block
         if (tid < 12) {
             const bool act = tid < 3 * nc;
-            const int f = act ? feet[tid / 3] : 0, r = tid % 3;
+            const int f = act ? feet.pick(tid / 3) : 0, r = tid % 3;
             L.gam[tid] = (act && mode == 0) ? (L.Jdv[3 * f + r] + 2.0 * alpha * L.fvel[3 * f + r]) : 0.0;
             L.grf[tid] = 0.0;
         })
@@ -321,7 +323,7 @@ HD void wb_kkt_tail(WbCore& L, int m, const Feet4& feet, int mode) {
         _Pragma("unroll") for (int a = 0; a < NM; a++) z += xr[a] * hs_readlane(v, a);
         _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
         if (tid < 18) L.qdd[wb_pi(tid)] = z + ((mode == 1) ? L.x[18 + wb_pi(tid)] : 0.0);
-        if (tid < 12) { const double lm = tid < NM ? v : 0.0; L.lam[tid] = lm; if (tid < m) L.grf[3 * feet[tid / 3] + tid % 3] = lm; }
+        if (tid < 12) { const double lm = tid < NM ? v : 0.0; L.lam[tid] = lm; if (tid < m) L.grf[3 * feet.pick(tid / 3) + tid % 3] = lm; }
     })
 #endif
 }
@@ -501,7 +503,7 @@ HD double wb_constraint_sel(PhaseC& P, const WbCore& L, int c) {
     const double c0 = bt ? P.torque_limit : bs ? (up ? P.jspeed_ub : -P.jspeed_lb) : bj ? cj : -P.h_min;
     const double sg = bt ? (up ? 1.0 : -1.0) : (bh || !up) ? 1.0 : -1.0;
     const int i1l = bt ? OU + lo : bs ? OX + 24 + lo : bj ? OX + 6 + lo : OX + 2;
-    const int ig = lin ? 0 : c - P.go_grf, ga = ig / 5, gr = ig - 5 * ga, f = feet_of(P)[ga];
+    const int ig = lin ? 0 : c - P.go_grf, ga = ig / 5, gr = ig - 5 * ga, f = feet_of(P).pick(ga & 3);
     const int i1 = lin ? i1l : OG + 3 * f + 2, i2 = lin ? i1l : OG + 3 * f + (gr >= 3 ? 1 : 0);
     const double v1 = w[i1], v2 = w[i2];
     const double a = lin ? sg : (gr == 0 ? 1.0 : P.mu);
@@ -649,36 +651,44 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
     }
     if (tid < 64) S[200 + tid] = gmin;)
     RL_STAMP(4)
-    // every sum of the knot in ONE instruction stream: lane 0 the state terms, 1 the control terms, 2..4 the foot terms, 5 the squared defect,
-    // 6 the squared norm of the simulated state, 7..11 the ReB cost of constraint object lane-7 (SinglePhase.cpp:394-402) — each lane adds its
-    // own run of consecutive LDS entries in the reference's order (fixed trip count; entries past the run's end are other data of the knot,
-    // in bounds, and add 0); (first entry, length) of a run come out of packed constants by shifts, not out of a branch per role.  Lanes
-    // 16..19 fold a quarter of the partial minima each.
+    // every sum of the knot in ONE instruction stream of twelve steps: 23 lanes each add a run of at most twelve consecutive LDS entries -
+    //   lanes 0..2 the state terms (three runs of 12), 3 the control terms, 4..6 the foot terms, 7..9 the squared defect, 10..12 the squared norm
+    //   of the simulated state, 13 + 2 o + half the ReB cost of constraint object o (SinglePhase.cpp:394-402; an object has at most 24 constraints)
+    // - (first entry, length) of a run come out of packed constants by shifts, not out of a branch per role; entries past a run's end are other
+    // data of the knot (in bounds) and add 0.  The partial sums of a quantity are added in run order in the next phase (the reference adds the
+    // terms one by one: same terms, a different association - 1e-16-level).  Lanes 16..19 also fold a quarter of the partial minima.
     HS_PHASE(NT, {
         const double* w = reinterpret_cast<const double*>(&L);
         constexpr int OS = offsetof(WbCore, JX) / 8, OBAR = offsetof(WbCore, GG) / 8 + 288 + MAXG;
-        constexpr unsigned long long RUN_OFF = 0ull | 36ull << 8 | 48ull << 16 | 52ull << 24 | 56ull << 32 | 64ull << 40 | 100ull << 48,
-                                     RUN_LEN = 36ull | 12ull << 8 | 4ull << 16 | 4ull << 24 | 4ull << 32 | 36ull << 40 | 36ull << 48;
+        constexpr unsigned long long RUN_OFF0 = 0ull | 12ull << 8 | 24ull << 16 | 36ull << 24 | 48ull << 32 | 52ull << 40 | 56ull << 48 | 64ull << 56,      // lanes 0..7
+                                     RUN_OFF1 = 76ull | 88ull << 8 | 100ull << 16 | 112ull << 24 | 124ull << 32,                                       // lanes 8..12
+                                     RUN_LEN = 0xCCCCCC444CCCCull;                                                                                   // 4 bits per lane 0..12
         unsigned long long po = P.obj_off, pl = P.obj_sz; HS_PIN_S(po); HS_PIN_S(pl);
-        const bool fixed = tid < 7; const int sh = 8 * (fixed ? tid : (tid < 12 ? tid - 7 : 7));
-        const int off = (fixed ? OS : OBAR) + (int)(((fixed ? RUN_OFF : po) >> sh) & 255), n = (int)(((fixed ? RUN_LEN : pl) >> sh) & 255);
+        const bool fixed = tid < 13; const int ob = tid < 23 ? tid - 13 : 0, o = ob >> 1, half = ob & 1;
+        const int foff = (int)(((tid < 8 ? RUN_OFF0 : RUN_OFF1) >> (8 * (tid & 7))) & 255), flen = (int)((RUN_LEN >> (4 * (fixed ? tid : 0))) & 15);
+        const int osz = (int)((pl >> (8 * o)) & 255) - 12 * half, olen = (tid >= 13 && tid < 23) ? (osz < 0 ? 0 : osz > 12 ? 12 : osz) : 0;
+        const int off = fixed ? OS + foff : OBAR + (int)((po >> (8 * o)) & 255) + 12 * half, n = fixed ? flen : olen;
         double sum = 0;
-        _Pragma("unroll") for (int i = 0; i < 36; i++) { const double v = w[off + i]; sum += (i < n) ? v : 0.0; }
+        _Pragma("unroll") for (int i = 0; i < 12; i++) { const double v = w[off + i]; sum += (i < n) ? v : 0.0; }
         double sm = 0; const int mo = OS + 200 + 16 * (tid & 3);
         _Pragma("unroll") for (int i = 0; i < 16; i++) sm = fmin(sm, w[mo + i]);
-        if (tid < 12) S[140 + tid] = sum;
+        if (tid < 23) S[140 + tid] = sum;
         if (tid >= 16 && tid < 20) S[180 + tid] = sm;
-        if (tid == 5) so.dsq[slot] = sum;
-        if (tid == 6 && (sqrt(sum) > 1e6 || !(sum == sum))) fail_flag[b] = 1;   // SinglePhase.cpp:205
     })
-    HS_PHASE(NT, if (tid == 0) {          // running cost in the reference's order of additions
-        double l = 0.5 * S[140]; l += 0.5 * S[141]; l *= P.dt;
-        l += S[142]; l += S[143]; l += S[144];
+    HS_PHASE(NT, if (tid == 0) {          // running cost: the reference's order of additions between the quantities
+        const double lq = (S[140] + S[141]) + S[142];
+        double l = 0.5 * lq; l += 0.5 * S[143]; l *= P.dt;
+        l += S[144]; l += S[145]; l += S[146];
         if (wr) P.lbase[kk] = l;
-        if (reb_active) { _Pragma("unroll") for (int gI = 0; gI < 5; gI++) if (gI < P.nobj) l += P.dt * S[147 + gI]; }
+        if (reb_active) { _Pragma("unroll") for (int gI = 0; gI < 5; gI++) if (gI < P.nobj) l += P.dt * (S[153 + 2 * gI] + S[154 + 2 * gI]); }
         if (wr) P.l[kk] = l; so.cost[slot] = l;
     } else if (tid == 16) {
         so.ming[slot] = fmin(fmin(S[196], S[197]), fmin(S[198], S[199])); so.maxh[slot] = 0.0;
+    } else if (tid == 32) {
+        so.dsq[slot] = (S[147] + S[148]) + S[149];
+    } else if (tid == 48) {
+        const double nsq = (S[150] + S[151]) + S[152];
+        if (nsq > 1e12 || !(nsq == nsq)) fail_flag[b] = 1;   // ||Xsim|| > 1e6 (SinglePhase.cpp:205)
     })
     RL_STAMP(5)
 }
