@@ -312,16 +312,21 @@ HD void wb_kkt_tail(WbCore& L, int m, const Feet4& feet, int mode) {
     // entry just finished travels by lane broadcast, the factor entries each lane needs are preloaded from LDS
     HS_PHASE(NT, {
         const int i12 = tid < NM ? tid : NM - 1, i18 = tid < 18 ? tid : 17;
-        double lgr[NM], lgc[NM], xr[NM], lmc[18];
+        double lgr[NM], lgc[NM], xr[NM], lmc[6], lleg[3];
         _Pragma("unroll") for (int k = 0; k < NM; k++) { lgr[k] = L.LG()[i12 * 12 + k]; lgc[k] = L.LG()[k * 12 + i12]; xr[k] = L.Xm()[i18 * 12 + k]; }
-        _Pragma("unroll") for (int k = 0; k < 18; k++) lmc[k] = L.M[k * 18 + i18];
+        const int lg = i18 < 12 ? i18 / 3 : 3, jl = i18 - 3 * lg;            // leg and joint of the lane's row (base rows: lg = 3 keeps the addresses valid, jl >= 3)
+        _Pragma("unroll") for (int k = 0; k < 6; k++) lmc[k] = L.M[(12 + k) * 18 + i18];            // column i18 of the factor: base rows ...
+        _Pragma("unroll") for (int j = 0; j < 3; j++) lleg[j] = L.M[(3 * lg + j) * 18 + i18];        // ... and the rows of the lane's own leg
         const double rg = L.rdG[i12], rm = L.rdM[i18];
         double v = L.rhs[i12];
         _Pragma("unroll") for (int k = 0; k < NM; k++) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid > k) ? v - lgr[k] * xk : v); }
         _Pragma("unroll") for (int k = NM - 1; k >= 0; k--) { const double xk = hs_readlane(v * rg, k); v = (tid == k) ? xk : ((tid < k) ? v - lgc[k] * xk : v); }
         double z = L.a0[i18];
         _Pragma("unroll") for (int a = 0; a < NM; a++) z += xr[a] * hs_readlane(v, a);
-        _Pragma("unroll") for (int k = 17; k >= 0; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k] * xk : z); }
+        // L^T qdd = z: the base rows one by one, then the third, second, first joint of EVERY leg at once (the factor has no entries between
+        // legs; the finished entry travels inside the leg by ds_bpermute) - 9 dependent steps instead of 18
+        _Pragma("unroll") for (int k = 17; k >= 12; k--) { const double xk = hs_readlane(z * rm, k); z = (tid == k) ? xk : ((tid < k) ? z - lmc[k - 12] * xk : z); }
+        _Pragma("unroll") for (int j = 2; j >= 0; j--) { const double xk = hs_bperm(z * rm, 3 * lg + j); z = (tid < 12 && jl == j) ? xk : ((tid < 12 && jl < j) ? z - lleg[j] * xk : z); }
         if (tid < 18) L.qdd[wb_pi(tid)] = z + ((mode == 1) ? L.x[18 + wb_pi(tid)] : 0.0);
         if (tid < 12) { const double lm = tid < NM ? v : 0.0; L.lam[tid] = lm; if (tid < m) L.grf[3 * feet.pick(tid / 3) + tid % 3] = lm; }
     })
@@ -514,8 +519,9 @@ HD double wb_constraint_sel(PhaseC& P, const WbCore& L, int c) {
 HD double reb_barrier1(double g, double delta) {
     const bool above = g > delta;
     const double lg = log(above ? g : delta);
-    const double t = (g - 2 * delta) / delta;
-    return above ? -lg : .5 * (t * t - 1) - lg;
+    double q = 0.0;
+    if (!above) { const double t = (g - 2 * delta) / delta; q = .5 * (t * t - 1); }     // (a wave whose constraints all sit above their delta skips the division)
+    return above ? -lg : q - lg;
 }
 
 struct SlotOut { double* cost; double* dsq; double* ming; double* maxh; };   // per (problem, slot) partials
