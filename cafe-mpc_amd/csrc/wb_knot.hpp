@@ -965,16 +965,21 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         HS_WPHASE_W(0, if (tid < 48) {
         const int d = tid;
         double top[18], bot[12];
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[wb_pi(i) * WT + d] + ((d < 18) ? D.W[wb_pi(i) * WT + 36 + d] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
-        _Pragma("unroll")
-        for (int a = 0; a < 12; a++) {
-            bot[a] = 0.0;
-            if (a < m) {      // uniform over the wave; the q / v halves differ only in which arrays feed the two terms: selects, no divergent branches
-                const int r = 3 * P.feet[a / 3] + a % 3, dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18;
-                const double vg = L.G()[r * 18 + c], vd = L.dvel()[r * 18 + c], vj = L.Jall[r * 18 + c];
-                const double t1 = dc < 18 ? vg : 2.0 * vd, t2 = dc < 18 ? vd : vj;       // footAccPartialDv == 2 footVelPartialDq
-                bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
+        {   // right-hand sides: every LDS read of the lane first, unconditionally (clamped addresses), then selects - a branch per entry would
+            // pay one exposed LDS round trip per entry (a single wave has nothing to hide it behind)
+            const int dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18, d2 = d < 18 ? d : 0;
+            double w1[18], w2[18], vg[12], vd[12], vj[12];
+            _Pragma("unroll") for (int i = 0; i < 18; i++) { w1[i] = D.W[wb_pi(i) * WT + dc]; w2[i] = D.W[wb_pi(i) * WT + 36 + d2]; }
+            const Feet4 ft = feet_of(P);
+            _Pragma("unroll") for (int a = 0; a < 12; a++) {
+                const int r = 3 * ft[a / 3] + a % 3;        // (uniform: scalar selects)
+                vg[a] = L.G()[r * 18 + c]; vd[a] = L.dvel()[r * 18 + c]; vj[a] = L.Jall[r * 18 + c];
+            }
+            HS_CBAR();
+            _Pragma("unroll") for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (w1[i] + ((d < 18) ? w2[i] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
+            _Pragma("unroll") for (int a = 0; a < 12; a++) {
+                const double t1 = dc < 18 ? vg[a] : 2.0 * vd[a], t2 = dc < 18 ? vd[a] : vj[a];       // footAccPartialDv == 2 footVelPartialDq
+                bot[a] = (a < m && d < 36) ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
             }
         }
         wb_kkt_column(L, D, top, bot, false, m);
@@ -1079,16 +1084,21 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
     HS_PHASE(NT, if (tid < 48) {
         const int d = tid;
         double top[18], bot[12];
-        _Pragma("unroll")
-        for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (D.W[wb_pi(i) * WT + d] + ((d < 18) ? D.W[wb_pi(i) * WT + 36 + d] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
-        _Pragma("unroll")
-        for (int a = 0; a < 12; a++) {
-            bot[a] = 0.0;
-            if (a < m) {      // uniform over the wave; the q / v halves differ only in which arrays feed the two terms: selects, no divergent branches
-                const int r = 3 * P.feet[a / 3] + a % 3, dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18;
-                const double vg = L.G()[r * 18 + c], vd = L.dvel()[r * 18 + c], vj = L.Jall[r * 18 + c];
-                const double t1 = dc < 18 ? vg : 2.0 * vd, t2 = dc < 18 ? vd : vj;       // footAccPartialDv == 2 footVelPartialDq
-                bot[a] = d < 36 ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
+        {   // right-hand sides: every LDS read of the lane first, unconditionally (clamped addresses), then selects - a branch per entry would
+            // pay one exposed LDS round trip per entry (a single wave has nothing to hide it behind)
+            const int dc = d < 36 ? d : 35, c = dc < 18 ? dc : dc - 18, d2 = d < 18 ? d : 0;
+            double w1[18], w2[18], vg[12], vd[12], vj[12];
+            _Pragma("unroll") for (int i = 0; i < 18; i++) { w1[i] = D.W[wb_pi(i) * WT + dc]; w2[i] = D.W[wb_pi(i) * WT + 36 + d2]; }
+            const Feet4 ft = feet_of(P);
+            _Pragma("unroll") for (int a = 0; a < 12; a++) {
+                const int r = 3 * ft[a / 3] + a % 3;        // (uniform: scalar selects)
+                vg[a] = L.G()[r * 18 + c]; vd[a] = L.dvel()[r * 18 + c]; vj[a] = L.Jall[r * 18 + c];
+            }
+            HS_CBAR();
+            _Pragma("unroll") for (int i = 0; i < 18; i++) top[i] = (d < 36) ? (w1[i] + ((d < 18) ? w2[i] : 0.0)) : ((wb_pi(i) == 6 + d - 36) ? 1.0 : 0.0);   // lanes 36+: tau tangent = -dJTF; entries in the legs-first order
+            _Pragma("unroll") for (int a = 0; a < 12; a++) {
+                const double t1 = dc < 18 ? vg[a] : 2.0 * vd[a], t2 = dc < 18 ? vd[a] : vj[a];       // footAccPartialDv == 2 footVelPartialDq
+                bot[a] = (a < m && d < 36) ? t1 + 2.0 * P.bg_alpha * t2 : 0.0;
             }
         }
         wb_kkt_column(L, D, top, bot, false, m);
