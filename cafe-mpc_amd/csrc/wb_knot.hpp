@@ -50,6 +50,7 @@ struct WbDeriv {   // LQ-only LDS; several short-lived matrices share storage (s
     double wp[12], wv[12], ep[12], ev[12];
     double LGs[144], rdGs[12];         // Schur factor of the contact solve, kept while GG holds the foot tangents
     double bdt[2 * MAXG];              // barrier derivative tables
+    unsigned long long tstamp1;        // (diagnostic stamps of the second wave)
     HD double* stC() { return JPW; }
     HD double* stB() { return JPW + 432; }
     HD double* stD() { return JPW + 648; }
@@ -85,6 +86,14 @@ __device__ unsigned long long g_lq_prof[16];
 #else
 #define LQ_STAMP(i)
 #define LQ_STAMP0()
+#endif
+// the second wave of the two-wave LQ knot times its own spans (thread 64)
+#if defined(LQ_PROF) && !defined(HS_HOST_EMU) && !defined(LQ_PROF_EXTERNAL)
+#define WB_W1_STAMP_BEGIN() if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 64) D.tstamp1 = clock64();
+#define WB_W1_STAMP_END(i) if (blockIdx.x == HS_PROF_BLOCK && threadIdx.x == 64) atomicAdd(&g_lq_prof[i], clock64() - D.tstamp1);
+#else
+#define WB_W1_STAMP_BEGIN()
+#define WB_W1_STAMP_END(i)
 #endif
 // LQ-program aliases into WbCore: Cst = [Jc|Xm] (432), dacc = G.., dvel = G+216 (G,LG,gval,bar = 432)
 
@@ -423,6 +432,7 @@ HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double 
         }
     };
     HS_PHASE(NT,
+        WB_W1_STAMP_BEGIN()
         if (tid < 60 && !(q_only && ((tid >= 12 && tid < 36) || tid >= 48))) {
             const int t = tid; int seed, leg, slot = 0; bool part = t < 36;
             if (t < 12) { seed = base_seed(t >> 2); leg = t & 3; slot = t; }
@@ -449,7 +459,8 @@ HD void wb_dpass(WbCore& L, WbDeriv& D, const ModelDev& md, double grav, double 
         for (int e = tid; e < 108; e += NT) { const int sd = e / 18, i = e % 18; D.W[i * WT + (sd < 3 ? sd : 33 + sd)] = 0.0; }
         for (int e = tid; e < 36; e += NT) { const int j = e / 12, r = e % 12; L.dacc()[r * 18 + j] = 0.0; L.dvel()[r * 18 + j] = 0.0; }
         // two-wave LQ knot: wave 1 (done with the shorter round) factors the Gram matrix the cache delivered, for the column solves
-        if (NT >= 128 && chol_g && tid >= 64) WB_CHOL_G(D.LGs, D.rdGs, tid - 64);)
+        if (NT >= 128 && chol_g && tid >= 64) WB_CHOL_G(D.LGs, D.rdGs, tid - 64);
+        WB_W1_STAMP_END(6))
     HS_PHASE(NT, if (tid < (q_only ? 6 : 12)) {
         const int seed = base_seed(tid), tq = seed < 18 ? seed : seed >= 36 ? seed - 36 : -1;
         V3<Dual> fb = {Dual(0.0), Dual(0.0), Dual(0.0)}, nb = fb;
@@ -1002,6 +1013,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         // wave 1.  Scratch in the free Jc block of JX (the columns only read Xm): [0,36) lx without the foot terms | [36,72) diagonal
         // additions | [72,84) luu diagonal | [84,120) lyy 3x3 blocks (r' + 3 column) | [120,156) foot-cost gradient (emulator only)
         double* const T1 = L.Jc();
+        WB_W1_STAMP_BEGIN()
         HS_WPHASE_W(1, wb_cost_blocks_lane(S, P, false, tid);
             if (tid < 36) {
                 const int d = tid;
@@ -1070,6 +1082,7 @@ HD void wb_lq_knot(WbLqLds& S, PhaseC& P, const ModelDev& md, int b, int k, int 
         HS_WPHASE_W(1, store_image<64, 144, 12>(P.luu + kk * P.rs, tid, [&](int, int r, int c) { return r == c ? T1[72 + r] : 0.0; });
                        store_image<64, 144, 12>(P.lyy + kk * P.rs, tid, [&](int, int r, int c) { return (r / 3 == c / 3) ? T1[84 + (r % 3) + 3 * c] : 0.0; });)
         // wave 1 has been done for a while when wave 0 leaves the column solves: both copy A, B, C, D out
+        WB_W1_STAMP_END(5)      // wave 1: its cost partials, start to end
         hs_phase_sync_all<NT>();
         HS_PHASE_L(NT,
             store_image<NT, 648, 18>(P.A + kk * P.rs, tid, [&](int, int r, int c) { return D.W[WR0 + r * 36 + c]; });     /* rows 18..35 of A (the upper rows are [I, dt I]) */

@@ -49,7 +49,7 @@ elif hasattr(lib, "hsddp_debug_lq_prof"):
     lib.hsddp_debug_lq_prof(buf, 1)
     s.LQ_approximation(opt)
     lib.hsddp_debug_lq_prof(buf, 0)
-    names = ["terms(P pass)", "kkt_direct + keep", "dpass", "A/C columns", "store A,B,C,D", "cost partials lxx", "lu/luu/ly/lyy",
+    names = ["terms(P pass)", "kkt_direct + keep", "dpass", "A/C columns", "store A,B,C,D", "cost partials lxx (two-wave knot: wave 1, all its cost partials)", "lu/luu/ly/lyy (two-wave knot: wave 1, kinematic round + Schur factor)",
              "kkt: select", "kkt: chol M", "kkt: X, y, gram", "kkt: chol G", "load phase"]
     tot = sum(buf)
     for i, n in enumerate(names):
