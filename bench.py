@@ -236,7 +236,7 @@ def main():
             achieved = per_launch_bytes / (ms / n * 1e-3) / 1e9
             traffic = None
             tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            if os.path.exists(tf):
+            if os.path.exists(tf) and not args.hkd:      # (the counters were collected on the whole-body workload: no figure for --hkd)
                 traffic = json.load(open(tf)).get(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
