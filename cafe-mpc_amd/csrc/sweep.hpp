@@ -38,7 +38,7 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 #define HS_STR_(x) #x
 #define HS_UNROLL_N(n) _Pragma(HS_STR_(unroll n))
 #ifndef SW_LDLT_NB
-#define SW_LDLT_NB ((M <= 12) ? 2 : 1)
+#define SW_LDLT_NB ((M <= 12 || sizeof(R) == 4) ? 2 : 1)
 #endif
 #ifndef SW_MINB
 #define SW_MINB 2
