@@ -170,6 +170,7 @@ HD double hs_bperm(double v, int src) {
     const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+HD float hs_bperm(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(4 * src, __float_as_int(v))); }
 // Cholesky of the 18 x 18 whole-body mass matrix in the legs-first order (rows 3l..3l+2: leg l, rows 12..17: floating base; no entries
 // between different legs), row i in lane i, in place.  The four 3 x 3 leg blocks do not depend on each other: their three column steps run
 // for all legs AT ONCE (pivot and multipliers travel inside a leg by ds_bpermute), so the dependent chain is 3 + 12 short + 6 column steps

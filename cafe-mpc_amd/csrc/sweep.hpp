@@ -180,7 +180,15 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
     })
 #else
     static_assert(M <= 32, "one row per lane");
+#if defined(SW_PROF)
+#define SW_LSTAMP(i) { if (blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(&g_sw_prof[i], t_ - tl_); tl_ = t_; } }
+#else
+#define SW_LSTAMP(i)
+#endif
     HS_WPHASE({
+#if defined(SW_PROF)
+        unsigned long long tl_ = clock64();
+#endif
         const bool act = tid < M; const int me = act ? tid : M - 1;       // idle lanes mirror the last row (all 64 lanes run the broadcasts)
         // ---- pivot order
         R dg[M];
@@ -189,19 +197,23 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
         int rank = 0; bool tie = false;
         _Pragma("unroll") for (int j = 0; j < M; j++) { const bool eq = (dg[j] == mine) && (j != me); rank += (dg[j] > mine || (eq && j < me)) ? 1 : 0; tie = tie || eq; }
         if (__builtin_amdgcn_ballot_w64(tie && act) == 0ull) { if (act) iw[rank] = me; }
-        else {      // exact ties: Eigen's selection with swaps, literally, on wave-uniform registers
-            R v[M]; int ix[M];
-            _Pragma("unroll") for (int j = 0; j < M; j++) { v[j] = dg[j]; ix[j] = j; }
+        else {      // exact ties (symmetric problems: every kinodynamic knot): Eigen's selection with swaps, literally.  Lane p holds the entry at POSITION p
+            // of the working diagonal as (original index, sorted positions [gt, ge) its value class occupies): the maxima are taken class by class, so
+            // at step k the largest remaining value is the class with gt <= k < ge - no reduction; its FIRST position >= k by ballot, swap with k
+            int gt = 0, ge = 0;
+            _Pragma("unroll") for (int j = 0; j < M; j++) { gt += (dg[j] > mine) ? 1 : 0; ge += (dg[j] >= mine) ? 1 : 0; }
+            int ixp = me; if (!act) { gt = M; ge = M; }
             _Pragma("unroll") for (int k = 0; k < M; k++) {
-                int big = k; R best = v[k];
-                _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool bgr = v[i] > best; best = bgr ? v[i] : best; big = bgr ? i : big; }
-                const R vk = v[k]; const int ik = ix[k]; int ib = ik;
-                _Pragma("unroll") for (int i = k + 1; i < M; i++) { const bool hit = (i == big); ib = hit ? ix[i] : ib; v[i] = hit ? vk : v[i]; ix[i] = hit ? ik : ix[i]; }
-                v[k] = best; ix[k] = ib;
-                if (tid == 0) iw[k] = ib;
+                const unsigned long long at = __builtin_amdgcn_ballot_w64(tid >= k && gt <= k && k < ge);
+                const int big = (int)__builtin_ctzll(at);
+                const int ik = __builtin_amdgcn_readlane(ixp, k), gk = __builtin_amdgcn_readlane(gt, k), ek = __builtin_amdgcn_readlane(ge, k);
+                const int ib = __builtin_amdgcn_readlane(ixp, big), gb = __builtin_amdgcn_readlane(gt, big), eb = __builtin_amdgcn_readlane(ge, big);
+                ixp = (tid == k) ? ib : ((tid == big) ? ik : ixp); gt = (tid == k) ? gb : ((tid == big) ? gk : gt); ge = (tid == k) ? eb : ((tid == big) ? ek : ge);
             }
+            if (act) iw[tid] = ixp;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SW_LSTAMP(9)
         int pv[M]; int myrank = 0;
         _Pragma("unroll") for (int k = 0; k < M; k++) { pv[k] = iw[k]; myrank = (pv[k] == me) ? k : myrank; }
         const int prow = iw[me];
@@ -213,6 +225,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
         //      the other rows travel by constant-lane broadcasts: a[k] -= L(me,j) * (D_j L(k,j)).  Same pivots and multipliers as Eigen's
         //      left-looking loops (A(k,k) -= L temp, A21 = (A21 - A20 temp) / A(k,k)) up to the association of the partial sums; quotients
         //      by the pivot as multiplications by its reciprocal.  Multipliers and reciprocal pivots go straight to LDS (row me of Lw).
+        SW_LSTAMP(10)
         bool anyneg = false;
         _Pragma("unroll") for (int j = 0; j < M; j++) {
             const R d = hs_readlane(arow[j], j);
@@ -223,6 +236,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             if (act) { if (me > j) Lw[me * M + j] = lij; else if (me == j) Lw[j * M + j] = rd; }
             _Pragma("unroll") for (int k = j + 1; k < M; k++) arow[k] -= lij * hs_readlane(arow[j], k);
         }
+        SW_LSTAMP(11)
         if (tid == 0 && anyneg) *ok = 0;       // isPositive(): no negative pivot (Eigen's sign bookkeeping ends in PositiveSemiDef / ZeroSign exactly then)
         // ---- column `me` of the inverse: P e_me is the unit vector at position myrank.  The factor row of the next step is fetched
         //      (broadcast reads) while the current row's multiply-add chain runs: a single wave has nothing else to hide the LDS latency behind.
@@ -239,6 +253,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             HS_PIN(sacc);       // (the row's chain is evaluated HERE: otherwise every row's loads are issued first and their values spill)
             y[k] = sacc;
         }
+        SW_LSTAMP(12)
         _Pragma("unroll") for (int k = 0; k < M; k++) y[k] = y[k] * Lw[k * M + k];
         _Pragma("unroll") for (int k = M - 1; k >= 0; k--) {
             if (NB == 2) { if (k > 0) { _Pragma("unroll") for (int j = k; j < M; j++) lr[(k - 1) % NB][j] = Lw[j * M + (k - 1)]; } }
@@ -250,6 +265,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             y[k] = sacc;
         }
         if (act) { _Pragma("unroll") for (int k = 0; k < M; k++) NI[pv[k] + LD * me] = -y[k]; }
+        SW_LSTAMP(13)
     })
 #endif
 }

@@ -33,7 +33,7 @@ if hasattr(lib, "hsddp_debug_sweep_prof"):
     s.backward_sweep(0.0)
     lib.hsddp_debug_sweep_prof(buf, 0)
     names = ["commit + next fetch", "phase 1: HA, HB, lC, lD", "phase 2: Qxx, Qux, Quu", "reg + store Qu/Quu/Qux", "chol + K, dU solves", "symmetrise Qxx", "ok check",
-             "H, G update", "store K"]
+             "H, G update", "store K", "  LDLT: pivot order", "  LDLT: permuted row", "  LDLT: factorisation", "  LDLT: forward solves", "  LDLT: scale, backward solves, store"]
     tot = sum(buf)
     for i, n in enumerate(names):
         print(f"  stamp {i} {n:26s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
