@@ -57,13 +57,15 @@ __device__ inline bool masked_out(const ProbState& s, int mask) {
 // Used for the young phases the receding-horizon update creates (SS_set empty, MHPCProblem.cpp:340-351; first > 0, stops at the next
 // phase with shooting nodes) and for the whole horizon when option.MS is false (MultiPhaseDDP.cpp:65-68; first = 0, descriptors with
 // every shooting flag cleared).  On entry the state to start from is in L.xnext (whole-body phase) / in Xsim[0] of the phase (SRB, HKD).
-__device__ __forceinline__ void rollout_chain(WbCore& L, PhaseC* ph, int nph, int first, const ModelDev& md, int b, int nslots, double eps, const OptDev& opt, SlotOut so,
+template <bool WBM, class LDS> __device__ __forceinline__ void rollout_chain(LDS& L, PhaseC* ph, int nph, int first, const ModelDev& md, int b, int nslots, double eps, const OptDev& opt, SlotOut so,
                                               size_t slot_base, int* fail, bool wr) {
     for (int pj = first; pj < nph && !ph[pj].shooting; pj++) {
         PhaseC& Q = ph[pj]; PhaseC* Qn = pj + 1 < nph ? &ph[pj + 1] : nullptr; const size_t s0 = slot_base + Q.slot0;
-        if (Q.model == HSDDP_MODEL_WB) {
+        if (WBM && Q.model == HSDDP_MODEL_WB) {
+            if constexpr (WBM) {
             for (int kq = 0; kq < Q.h; kq++) wb_rollout_knot<64>(L, Q, md, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true, wr);
             wb_rollout_terminal<64>(L, Q, Qn, md, b, eps, opt.AL_active, so, s0 + Q.h, true, wr);
+            }
         } else if (Q.model == HSDDP_MODEL_SRB) {      // (reads the simulated state back from Xsim: not available to probes, see hsddp_solve)
             SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
             for (int kq = 0; kq < Q.h; kq++) srb_rollout_knot<64>(Ls, Q, b, kq, eps, opt.ReB_active, nullptr, so, s0 + kq, fail, true, wr);
@@ -83,15 +85,18 @@ __device__ __forceinline__ void rollout_chain(WbCore& L, PhaseC* ph, int nph, in
 constexpr int MAXCAND = 12;
 struct EpsList { double e[MAXCAND]; int n, writer, from_state; };
 
-__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, int batch, ModelDev md,
-                                               EpsList el, OptDev opt, const double* x0, SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
+// LDS of the kernels instantiated WITHOUT the whole-body model (kinodynamic / single-rigid-body handles): 8 KB instead of 16 / 40 KB, so that
+// their small knots are not held to the whole-body kernels' two waves per SIMD
+union RedLds { HkdLds h; SrbLds s; };
+#define ROLL_ARGS const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, int batch, ModelDev md, EpsList el, OptDev opt, const double* x0, SlotArrays sa, \
+                  const ProbState* st, int mask, int* fail, unsigned long long* units
+template <bool WBM, class LDS> __device__ __forceinline__ void rollout_body(LDS& L, ROLL_ARGS) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int per = batch * nslots;
     const int c = blockIdx.x / per, r = blockIdx.x - c * per;
     const int b = r / nslots, s = r - b * nslots;
     if (masked_out(st[b], mask)) return;
     if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);     // knots this launch rolls out (measurement only)
-    __shared__ WbCore L;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
     const size_t cbase = (size_t)c * per;                       // slice of candidate c in the slot arrays
@@ -104,7 +109,7 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, i
     if (!ph[0].shooting) {       // single shooting over the whole horizon (option.MS = false): the wave of slot 0 walks every phase
         if (s != 0) return;
         const int n0 = ph[0].n;
-        if (ph[0].model == HSDDP_MODEL_WB) { HS_PHASE(64, if (tid < 36) L.xnext[tid] = x0[(size_t)b * 36 + tid];) }
+        if (WBM && ph[0].model == HSDDP_MODEL_WB) { if constexpr (WBM) { HS_PHASE(64, if (tid < 36) L.xnext[tid] = x0[(size_t)b * 36 + tid];) } }
         else { HS_PHASE(64, if (tid < n0) ph[0].Xsim[(size_t)b * (ph[0].h + 1) * n0 + tid] = x0[(size_t)b * n0 + tid];) }
         chain_first = 0;
     } else {
@@ -119,14 +124,27 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(const PhaseDev* ph_, i
             SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
             if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail, false, wr);
             else srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot, false, wr);
-        } else {
+        } else if constexpr (WBM) {
             if (k < P.h) wb_rollout_knot<64>(L, P, md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, so, slot, fail, false, wr);
             else wb_rollout_terminal<64>(L, P, Pn, md, b, eps, opt.AL_active, so, slot, false, wr);
         }
     }
     // single-shooting phases from here on (young phases behind a terminal knot, or the whole horizon): ONE call site, one copy of the code
-    if (chain_first >= 0 && chain_first < nph && !ph[chain_first].shooting) rollout_chain(L, ph, nph, chain_first, md, b, nslots, eps, opt, so, slot_base, fail, wr);
+    if (chain_first >= 0 && chain_first < nph && !ph[chain_first].shooting) rollout_chain<WBM>(L, ph, nph, chain_first, md, b, nslots, eps, opt, so, slot_base, fail, wr);
 }
+#define ROLL_PASS ph_, nph, slot_phase, slot_k, nslots, batch, md, el, opt, x0, sa, st, mask, fail, units
+__global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(ROLL_ARGS) { __shared__ WbCore L; rollout_body<true>(L, ROLL_PASS); }
+// handles without whole-body phases (has_hkd): no whole-body code, 8 KB of LDS, no register cap
+// (measured on config 5, waves per SIMD rollout / LQ: none/none 111.6 k it/s, 3/- 117.7 k, 4/- 121.9 k, 4/5 122.1 k, 5/5 122.5 k; 8 KB of LDS allow five)
+#ifndef ROLL_HKD_WPE
+#define ROLL_HKD_WPE 4
+#endif
+#ifdef ROLL_HKD_WPE
+#define ROLL_HKD_ATTR __attribute__((amdgpu_waves_per_eu(ROLL_HKD_WPE, ROLL_HKD_WPE)))
+#else
+#define ROLL_HKD_ATTR
+#endif
+__global__ void __launch_bounds__(64) ROLL_HKD_ATTR k_rollout_hkd(ROLL_ARGS) { __shared__ RedLds L; rollout_body<false>(L, ROLL_PASS); }
 
 // Batched line search, decision step (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:108-131, for the candidates of one probe launch): per
 // problem the candidates are examined IN ORDER - reduction of the slice's partials, merit, Armijo test - exactly as if they had been
@@ -181,28 +199,41 @@ __global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArray
     }
 }
 
-__global__ void __launch_bounds__(LQ_NT) LQ_ATTR k_lq(const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt,
-                                          const ProbState* st, int mask, int use_cache, unsigned long long* units) {
+#define LQ_ARGS const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, ModelDev md, OptDev opt, const ProbState* st, int mask, int use_cache, unsigned long long* units
+template <bool WBM, int NT, class LDS> __device__ __forceinline__ void lq_body(LDS& L, LQ_ARGS) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int b = blockIdx.x / nslots, s = blockIdx.x % nslots;
     if (masked_out(st[b], mask)) return;
     if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);
-    __shared__ WbLqLds L;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
     if (P.model == HSDDP_MODEL_HKD) {
         HkdLds& Lh = *reinterpret_cast<HkdLds*>(&L);
-        if (k < P.h) hkd_lq_knot<LQ_NT>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<LQ_NT>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+        if (k < P.h) hkd_lq_knot<NT>(Lh, P, b, k, opt.ReB_active); else hkd_lq_terminal<NT>(Lh, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
         return;
     }
     if (P.model == HSDDP_MODEL_SRB) {
         SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
-        if (k < P.h) srb_lq_knot<LQ_NT>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<LQ_NT>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
+        if (k < P.h) srb_lq_knot<NT>(Ls, P, b, k, opt.ReB_active); else srb_lq_terminal<NT>(Ls, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, b);
         return;
     }
-    if (k < P.h) wb_lq_knot<LQ_NT>(L, P, md, b, k, opt.ReB_active, use_cache != 0);
-    else wb_lq_terminal<LQ_NT>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+    if constexpr (WBM) {
+        if (k < P.h) wb_lq_knot<NT>(L, P, md, b, k, opt.ReB_active, use_cache != 0);
+        else wb_lq_terminal<NT>(L, P, pi + 1 < nph ? &ph[pi + 1] : nullptr, md, b, opt.AL_active);
+    }
 }
+#define LQ_PASS ph_, nph, slot_phase, slot_k, nslots, md, opt, st, mask, use_cache, units
+__global__ void __launch_bounds__(LQ_NT) LQ_ATTR k_lq(LQ_ARGS) { __shared__ WbLqLds L; lq_body<true, LQ_NT>(L, LQ_PASS); }
+// handles without whole-body phases: one wave per knot, 8 KB of LDS, no register cap
+#ifndef LQ_HKD_WPE
+#define LQ_HKD_WPE 5
+#endif
+#ifdef LQ_HKD_WPE
+#define LQ_HKD_ATTR __attribute__((amdgpu_waves_per_eu(LQ_HKD_WPE, LQ_HKD_WPE)))
+#else
+#define LQ_HKD_ATTR
+#endif
+__global__ void __launch_bounds__(64) LQ_HKD_ATTR k_lq_hkd(LQ_ARGS) { __shared__ RedLds L; lq_body<false, 64>(L, LQ_PASS); }
 
 // cost-only refresh from stored g / h with the CURRENT ReB / AL parameters (SinglePhase::compute_cost, SinglePhase.cpp:236-262)
 __global__ void __launch_bounds__(64) k_cost(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, int nslots, OptDev opt, SlotArrays sa,
@@ -777,7 +808,7 @@ static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}
 static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotArrays& sa, const OptDev& o, int mask, const char* name, int unit = UNIT_ROLLOUT) {
     Timed t(h, name);
     hipMemsetAsync(h->d_fail, 0, (size_t)h->batch * el.n * sizeof(int), h->stream);
-    hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k,
+    hipLaunchKernelGGL(h->has_hkd ? k_rollout_hkd : k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k,
                        h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit);
 }
 static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask, bool eps_from_state = false) {
@@ -797,8 +828,10 @@ static int ensure_probe_arrays(hsddp_handle* h, int cands) {
 }
 static void launch_lq(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_lq");
-    hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(LQ_NT), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
-                       h->cache_valid ? 1 : 0, h->d_units + UNIT_LQ);
+    if (h->has_hkd) hipLaunchKernelGGL(k_lq_hkd, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
+                                       0, h->d_units + UNIT_LQ);
+    else hipLaunchKernelGGL(k_lq, dim3((unsigned)((size_t)h->batch * h->nslots)), dim3(LQ_NT), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k, h->nslots, h->md, o, h->d_st, mask,
+                            h->cache_valid ? 1 : 0, h->d_units + UNIT_LQ);
 }
 static void launch_cost(hsddp_handle* h, const OptDev& o, int mask) {
     Timed t(h, "k_cost");
