@@ -233,7 +233,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             rd = (fabs(d) > TOL) ? rd : 0.0;
             anyneg = anyneg || (d < 0.0);
             const R lij = (fabs(d) > 0.0) ? arow[j] * rd : arow[j];
-            if (act) { if (me > j) Lw[me * M + j] = lij; else if (me == j) Lw[j * M + j] = rd; }
+            if (act && me >= j) Lw[me * M + j] = (me == j) ? rd : lij;      // multiplier, or the reciprocal pivot on the diagonal: one predicated store
             _Pragma("unroll") for (int k = j + 1; k < M; k++) arow[k] -= lij * hs_readlane(arow[j], k);
         }
         SW_LSTAMP(11)
