@@ -61,6 +61,18 @@ int setup_phase(Mem& mem, const hsddp_phase_desc_t& d, const hsddp_phase_desc_t*
     up(&P.xr, d.xr, h1 * n); up(&P.ur, d.ur, h1 * m); up(&P.yr, py ? d.yr : nullptr, h1 * std::max<size_t>(py, 1));
     up(&P.foot_pos, d.foot_pos, h1 * 12); up(&P.foot_vel, d.foot_vel, h1 * 12); up(&P.body_pos, d.body_pos, h1 * 3);
     { void* p = mem.alloc(h1 * 4 * sizeof(int)); if (!p) ok = false; else { if (d.ref_contact) mem.upload(p, d.ref_contact, h1 * 4 * sizeof(int)); P.ref_contact = (const int*)p; } }
+    if (d.model == HSDDP_MODEL_WB) {      // packed per-knot reference record (PhaseDev::rref)
+        std::vector<double> rr(h1 * 80, 0.0);
+        for (size_t k = 0; k < h1; k++) {
+            double* r = rr.data() + k * 80;
+            if (d.xr) for (int i = 0; i < 36; i++) r[i] = d.xr[k * 36 + i];
+            if (d.ur) for (int i = 0; i < 12; i++) r[36 + i] = d.ur[k * 12 + i];
+            if (d.foot_vel) for (int i = 0; i < 12; i++) r[48 + i] = d.foot_vel[k * 12 + i];
+            if (d.ref_contact) for (int i = 0; i < 4; i++) r[60 + i] = (double)d.ref_contact[k * 4 + i];
+            for (int i = 0; i < 12; i++) r[64 + i] = (d.foot_pos ? d.foot_pos[k * 12 + i] : 0.0) - (d.body_pos ? d.body_pos[k * 3 + i % 3] : 0.0);
+        }
+        up(&P.rref, rr.data(), h1 * 80);
+    }
     auto al = [&](double** dst, size_t cnt) { void* p = mem.alloc(std::max<size_t>(cnt, 1) * 8); if (!p) ok = false; *dst = (double*)p; };
     double** sx[] = {&P.X, &P.Xbar, &P.Xsim, &P.Defect, &P.Defect_bar, &P.dX, &P.G};
     for (auto p : sx) al(p, B * h1 * n);

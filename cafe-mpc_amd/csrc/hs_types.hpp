@@ -47,6 +47,9 @@ struct PhaseDev {
     // reference arrays shared by the batch: (h+1) x width
     const HS_GLOBAL double *xr, *ur, *yr, *foot_pos, *foot_vel, *body_pos;
     const HS_GLOBAL int* ref_contact;
+    // whole-body phases: the references of knot k in ONE record of 80 doubles (one base pointer for the rollout knot's first reads):
+    // [0,36) xr | [36,48) ur | [48,60) foot_vel | [60,64) ref_contact as doubles | [64,76) foot_pos - body_pos | [76,80) pad
+    const HS_GLOBAL double* rref;
     // trajectories
     HS_GLOBAL double *X, *Xbar, *Xsim, *Defect, *Defect_bar, *dX, *G;           // (h+1) x n
     HS_GLOBAL double *U, *Ubar, *dU, *Qu;                                        // h x m

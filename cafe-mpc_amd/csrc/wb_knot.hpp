@@ -581,10 +581,10 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         // addresses are picked per lane, idle lanes read a valid dummy
         const int g = tid < 36 ? 0 : tid < 48 ? 1 : tid < 60 ? 2 : 3, i = tid < 36 ? tid : tid < 48 ? tid - 36 : tid < 60 ? tid - 48 : 0;
         const double* pa = g == 0 ? P.Xbar + kx + i : (g == 1 && !ss) ? P.KdX + ku + i : P.Xbar + kx; const double* pb = P.dX + kx + (g == 0 ? i : 0);
-        const double* pc = g == 0 ? P.xr + (size_t)k * 36 + i : g == 1 ? P.ur + (size_t)k * 12 + i : P.foot_vel + (size_t)k * 12 + i;
-        const double* pd = g == 0 ? P.Xbar + kx + (ss ? 0 : 36) + i : g == 1 ? P.Ubar + ku + i : P.foot_pos + (size_t)k * 12 + i;
-        const double* pe = g == 0 ? P.dX + kx + (ss ? 0 : 36) + i : g == 1 ? P.dU + ku + i : P.body_pos + (size_t)k * 3 + i % 3;
-        const int rci = P.ref_contact[(size_t)k * 4 + (tid & 3)];
+        const double* rr = P.rref + (size_t)k * 80;          // the knot's references: one record, lane tid takes entry tid (+ the relative foot position)
+        const double* pc = rr + tid;
+        const double* pd = g == 0 ? P.Xbar + kx + (ss ? 0 : 36) + i : g == 1 ? P.Ubar + ku + i : rr + 64 + i;
+        const double* pe = g == 0 ? P.dX + kx + (ss ? 0 : 36) + i : g == 1 ? P.dU + ku + i : rr;
         double va = *pa, vb = *pb, vc = *pc, vd = *pd, ve = *pe;
         const double* pw = tid < 36 ? &P.q[tid] : &P.r[tid < 48 ? tid - 36 : 0];      // (one load: two would wait for each other where they merge)
         const double vw = *pw;
@@ -592,7 +592,6 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; er[q] = (c < P.ng) ? P.eps[kk * P.ng + c] : 0.0; dr[q] = (c < P.ng) ? P.delta[kk * P.ng + c] : 0.0; }
         if (ss) { Late& lt = late[HS_LANE(tid)]; _Pragma("unroll") for (int q = 0; q < 7; q++) { const int e = q * NT + tid; lt.kr[q] = (e < 432) ? P.K[kk * 432 + e] : 0.0; } }
         HS_CBAR();
-        if (tid >= 60) vc = (double)rci;
         if (tid < 36) {
             const double xb = va, x = ss ? L.xnext[tid] : xb + eps * vb;
             L.xb[tid] = xb; L.x[tid] = x; if (wr) P.X[kx + tid] = x;
@@ -602,7 +601,7 @@ HD void wb_rollout_knot(WbCore& L, PhaseC& P, const ModelDev& md, int b, int k, 
             if (ss) L.red[tid] = vd + eps * ve;
             else { const double u = vd + eps * (ve + va); L.u[i] = u; if (wr) P.U[ku + i] = u; L.tau[6 + i] = u; }
         }
-        else if (tid < 60) { L.tmp[tid] = vc; L.red[tid] = vd - ve; }     // reference foot position relative to the body (foot costs below)
+        else if (tid < 60) { L.tmp[tid] = vc; L.red[tid] = vd; }          // reference foot position relative to the body (foot costs below)
         else if (tid < 64) L.red[tid] = vc;                               // reference contact flags
         if (tid < 18) { L.acc[tid] = 0.0; if (ss || tid < 6) L.tau[tid] = 0.0; } if (tid < 12) L.fext[tid] = 0.0; if (tid < 48) L.wq[tid] = vw;
         _Pragma("unroll") for (int q = 0; q < 2; q++) { const int c = q * NT + tid; if (c < P.ng) { L.gval()[c] = er[q]; L.bar()[c] = dr[q]; } })
