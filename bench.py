@@ -241,8 +241,8 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
                     # what actually bounds the per-knot kernels (offline SQ counters, not measured by this run): fp64 VALU issue at two waves per SIMD
-                    "binding_resource": None if args.hkd else {"resource": "fp64 VALU issue", "simd_valu_utilisation": 0.63, "valu_instructions_per_rollout_knot": 3594,
-                                                               "source": "profiles/r02n_sq_counters.txt"},
+                    "binding_resource": None if args.hkd else {"resource": "fp64 VALU issue", "simd_valu_utilisation": 0.65, "valu_instructions_per_rollout_knot": 3251,
+                                                               "source": "profiles/r02p_sq_counters.txt"},
                     "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
                     "kernel_units_knots": s.kernel_units(),
                     "whole_iteration": {"alg_bytes_per_knot_iteration": alg_total, "achieved_GBs": alg_total * knots * iters_done / dt / 1e9 / world,
