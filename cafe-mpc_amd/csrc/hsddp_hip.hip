@@ -1114,9 +1114,9 @@ int hsddp_debug_lq_prof(unsigned long long* out16, int reset) {
 }
 #endif
 #ifdef SW_PROF
-int hsddp_debug_sweep_prof(unsigned long long* out16, int reset) {
-    hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sw_prof), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_sw_prof), z, sizeof(z)); }
+int hsddp_debug_sweep_prof(unsigned long long* out48, int reset) {
+    hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_sw_prof), 48 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[48] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_sw_prof), z, sizeof(z)); }
     return 0;
 }
 #endif

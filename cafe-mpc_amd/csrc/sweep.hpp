@@ -84,10 +84,12 @@ using SweepLds32 = SweepLdsRaw<float, 1>;      // kinodynamic + SRB phases of th
 
 // optional in-kernel stamps (diagnostic builds only: -DSW_PROF): cycles per phase group, block 0 / thread 0
 #if defined(SW_PROF) && !defined(HS_HOST_EMU)
-__device__ unsigned long long g_sw_prof[16];
+__device__ unsigned long long g_sw_prof[48];      // [0,16): phase stamps of thread 0 ; [16 + 4 p + w]: wave w's own time in MFMA phase p (start of the phase to its arrival at the barrier)
 #define SW_STAMP(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); atomicAdd(&g_sw_prof[i], t_ - SWC.t_last); SWC.t_last = t_; } }
 #define SW_STAMP0() { if (blockIdx.x == 0 && threadIdx.x == 0) SWC.t_last = clock64(); }
+#define SW_WSTAMP(p) { if (blockIdx.x == 0 && (tid & 63) == 0) atomicAdd(&g_sw_prof[16 + 4 * (p) + (tid >> 6)], clock64() - SWC.t_last); }
 #else
+#define SW_WSTAMP(p)
 #define SW_STAMP(i)
 #define SW_STAMP0()
 #endif
@@ -233,7 +235,10 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             rd = (fabs(d) > TOL) ? rd : 0.0;
             anyneg = anyneg || (d < 0.0);
             const R lij = (fabs(d) > 0.0) ? arow[j] * rd : arow[j];
-            if (act && me >= j) Lw[me * M + j] = (me == j) ? rd : lij;      // multiplier, or the reciprocal pivot on the diagonal: one predicated store
+            // multiplier, or the reciprocal pivot on the diagonal.  One predicated store for the 12 x 12 blocks (k_sweep 16.5 -> 16.2 ms); the 24 x 24
+            // blocks of the kinodynamic model measure better with the two-branch form (k_sweep32 418.8 against 441.6 ms per five launches)
+            if (M <= 12) { if (act && me >= j) Lw[me * M + j] = (me == j) ? rd : lij; }
+            else if (act) { if (me > j) Lw[me * M + j] = lij; else if (me == j) Lw[j * M + j] = rd; }
             _Pragma("unroll") for (int k = j + 1; k < M; k++) arow[k] -= lij * hs_readlane(arow[j], k);
         }
         SW_LSTAMP(11)
@@ -315,11 +320,14 @@ HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane, R dt) {
     constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM, AR = SweepLdsT<N, M, PY, R>::AR, LDA = SweepLdsT<N, M, PY, R>::LDA, A0 = SweepLdsT<N, M, PY, R>::A0;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16, TPd = TP > 0 ? TP : 1;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
-    constexpr int NTL = (t4 - W + 3) / 4;
+    // tiles dealt round-robin, t = W + 4 q - except for the whole-body sizes (16 tiles), where the per-wave stamps (tools/microbench.py, -DSW_PROF)
+    // put wave 3 (HA, HA, HB(32,0), lD) 1.3 k cycles behind wave 0 (HA, HA, HA, lC): the lD tile goes to wave 0
+    constexpr bool WBT = (t4 == 16 && t3 == 15);
+    constexpr int NTL = WBT ? (W == 0 ? 5 : W == 3 ? 3 : 4) : (t4 - W + 3) / 4;
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int t = W + 4 * q;
+        const int t = (WBT && W == 0 && q == 4) ? 15 : W + 4 * q;
         // HA = H A = H(:, A0:) A_low (+ H [I, dt I] when the upper rows of A are the forward-Euler identities) ; HB = H(:, A0:) B_low
         if (t < t1) { td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H + LDN * A0, LDN, S.A, LDA, AR, false, nullptr, 0, nullptr, 0, 0};
                       if (A0 > 0) { td[q].T = S.H; td[q].ldt = LDN; td[q].tmode = 1; td[q].tsplit = A0; td[q].tscale = dt; } }
@@ -387,6 +395,9 @@ template <int NT, int N, int M, int PY, class R, class LDS>
 HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
     using RL = RecLayout<N, M, PY>; using ST = SweepLdsT<N, M, PY, R>;
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
+    // lanes of the mat-vec chains that ride along with the tile phases (balance measured with the per-wave stamps, -DSW_PROF)
+    constexpr bool WBS = (N == 36 && M == 12 && PY == 12);
+    constexpr int GN0 = WBS ? 64 : 0, G0 = WBS ? 64 : NT - N, DV0 = WBS ? 64 + N : NT - N - 1, DU0 = WBS ? 64 + N + 1 : NT - N - 1 - M;
     constexpr int LDN = ST::LDN, LDM = ST::LDM, AR = ST::AR, LDA = ST::LDA, A0 = ST::A0;
     static_assert(sizeof(ST) <= sizeof(SS.raw), "the view fits the raw LDS block of its model set");
     ST& S = *reinterpret_cast<ST*>(SS.raw); SweepCtl& SWC = SS.c;
@@ -413,7 +424,10 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
             const int w = tid >> 6, lane = tid & 63;
             switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane, dtR); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane, dtR); break;
                          case 2: sweep_tiles1<2, N, M, PY, R>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane, dtR); }
-            if (tid < N) { R s = S.G[tid]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, tid, j, LDN) * S.def[j]; S.Gn[tid] = s; }
+            // (whole body: the Gnext chain rides on wave 1 - per-wave stamps show it 2.5 k cycles ahead of wave 0, which carries three of the nine HA
+            // tiles; the 24 / 12-row models deal two tiles to every wave and keep it on wave 0)
+            if (tid >= GN0 && tid < GN0 + N) { const int i = tid - GN0; R s = S.G[i]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; }
+            SW_WSTAMP(0)
         })
         SW_STAMP(1)
         // phase 2: Qxx - lxx = A^T HA + C^T lC (TN x TN, into the H block) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
@@ -435,6 +449,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
                 S.Qu[a] += s;
             }
+            SW_WSTAMP(1)
         })
         SW_STAMP(2)
         // (the regularisation of Quu and Qxx went onto the diagonals with the tiles' stores) ; store Qu / Quu / Qux as the reference keeps them
@@ -464,15 +479,16 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
             if (tid >= NT - M) { const int i = tid - (NT - M); R s = 0; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.LQ, i, t, LDM) * S.Qu[t]; S.dU[i] = s; }
             // lxx joins Qxx here, from the registers it was prefetched into (symmetric by construction; the symmetrisation of SinglePhase.cpp:376
             // has acted on the products): Qxx = lxx + A^T H A + C^T lyy C + reg I is complete before the next phase reads it
-            SW_RICCATI_LXX() if (k > 0) SW_RICCATI_FETCH_LXX(kk - 1))
+            SW_RICCATI_LXX() if (k > 0) SW_RICCATI_FETCH_LXX(kk - 1) SW_WSTAMP(2))
         // H = Qxx + Qux^T K ; G = Qx + Qux^T dU ; dV ; store K, dU, G
         HS_PHASE_L(NT,
             { const int w = tid >> 6, lane = tid & 63;      // H = Qxx + Qux^T K on the matrix cores: 9 tiles over 4 waves
               switch (w) { case 0: sweep_tiles3<0, N, M, PY, R>(S, lane); break; case 1: sweep_tiles3<1, N, M, PY, R>(S, lane); break;
                            case 2: sweep_tiles3<2, N, M, PY, R>(S, lane); break; default: sweep_tiles3<3, N, M, PY, R>(S, lane); } }
-            if (tid >= NT - N) { const int i = tid - (NT - N); R s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
-            else if (tid == NT - N - 1) { R dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
-            else if (tid >= NT - N - 1 - M) { const int a = tid - (NT - N - 1 - M); gdU[kk * M + a] = S.dU[a]; })
+            // (whole body: G, dV and the store of dU on wave 1 - two tiles and the shortest time in this phase; wave 3 carried them 1 k cycles behind)
+            if (tid >= G0 && tid < G0 + N) { const int i = tid - G0; R s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
+            else if (tid == DV0) { R dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
+            else if (tid >= DU0 && tid < DU0 + M) { const int a = tid - DU0; gdU[kk * M + a] = S.dU[a]; } SW_WSTAMP(3))
         SW_STAMP(7)
         HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N);)
         SW_STAMP(8)

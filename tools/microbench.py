@@ -28,13 +28,15 @@ for k, (ms, n) in sorted(kt.items()):
 import ctypes
 lib = pkg.load_hip_library()
 if hasattr(lib, "hsddp_debug_sweep_prof"):
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 48)()
     lib.hsddp_debug_sweep_prof(buf, 1)
     s.backward_sweep(0.0)
     lib.hsddp_debug_sweep_prof(buf, 0)
+    for p, nm in enumerate(["phase 1", "phase 2", "K, dU", "H, G update"]):
+        print(f"  waves' own time in {nm:12s}: " + "  ".join(f"w{w} {buf[16 + 4 * p + w] / 200:7.0f}" for w in range(4)) + "  cycles/knot")
     names = ["commit + next fetch", "phase 1: HA, HB, lC, lD", "phase 2: Qxx, Qux, Quu", "reg + store Qu/Quu/Qux", "chol + K, dU solves", "symmetrise Qxx", "ok check",
              "H, G update", "store K", "  LDLT: pivot order", "  LDLT: permuted row", "  LDLT: factorisation", "  LDLT: forward solves", "  LDLT: scale, backward solves, store"]
-    tot = sum(buf)
+    tot = sum(buf[:16])
     for i, n in enumerate(names):
         print(f"  stamp {i} {n:26s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
 if hasattr(lib, "hsddp_debug_lq_prof") and os.environ.get("ROLL_PROF"):
