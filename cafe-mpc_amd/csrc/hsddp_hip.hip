@@ -315,10 +315,13 @@ SWEEP_KERNEL(k_sweep, double, SW_SET_WB, SweepLds, SW_WB_WAVES)           // who
 SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)      // kinodynamic 24/24/0 phases, fp64
 // fp32 handles (hsddp_create_ex): fp32 LQ records, every product of the Riccati step on v_mfma_f32_16x16x4_f32, an LDS block a third the size
 // (kinodynamic 24/24/0 and single-rigid-body phases only: SinglePhase.cpp:565-567, HKDModel.h:33-61)
-SWEEP_KERNEL(k_sweep32, float, SW_SET_HKD, SweepLds32, 4)
+#ifndef SW_F32_WAVES
+#define SW_F32_WAVES 4
+#endif
+SWEEP_KERNEL(k_sweep32, float, SW_SET_HKD, SweepLds32, SW_F32_WAVES)
 LINEAR_KERNEL(k_linear, double, SW_SET_WB, SweepLds, SW_WB_WAVES)
 LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)
-LINEAR_KERNEL(k_linear32, float, SW_SET_HKD, SweepLds32, 4)
+LINEAR_KERNEL(k_linear32, float, SW_SET_HKD, SweepLds32, SW_F32_WAVES)
 
 // receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase / hsddp_reconfigure): one workgroup per (problem, destination knot).
 // Trajectories as SinglePhase::pop_front x shift + push_back_default do (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228); the per-knot
