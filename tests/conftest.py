@@ -44,3 +44,19 @@ def hip_lib():
 def golden():
     d = os.path.join(ROOT, "tests", "golden")
     return {f[:-4]: np.load(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".npz")}
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Book-keeping of the conditioning arbiter (tests/parity_common.py): every tolerance it widened in this session."""
+    import parity_common as pc
+    if not pc.GRANTS:
+        terminalreporter.write_line("[arbiter] no tolerance was widened in this session")
+        return
+    worst = {}
+    for (tag, f, i, tol, granted, own, err, sc) in pc.GRANTS:
+        k = (tag.split(" ")[0], f)
+        if k not in worst or granted > worst[k][1]:
+            worst[k] = (tol, granted, own, err, sc)
+    terminalreporter.write_line(f"[arbiter] {len(pc.GRANTS)} widened tolerances; largest grant per (comparison, field):")
+    for (tag, f), (tol, granted, own, err, sc) in sorted(worst.items()):
+        terminalreporter.write_line(f"[arbiter]   {tag:24s} {f:12s} plain {tol:.2e} -> granted {granted:.2e}  (oracle-vs-exact {own:.2e}, measured error {err if err is None else format(err, '.2e')}, scale {sc:.2e})")

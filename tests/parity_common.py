@@ -1,4 +1,17 @@
-"""Shared driver: run the same HS-DDP steps on two backends of the include/hsddp.h ABI and compare fields."""
+"""Shared driver: run the same HS-DDP steps on two backends of the include/hsddp.h ABI and compare fields.
+
+Tolerances: every field rtol x its scale, the gains K absolute (north_star: ||K_gpu - K_cpu||_inf < 1e-6).
+
+Conditioning arbiter (`exact=`): the long-double build of the oracle run through the same steps.  Where the fp64 ORACLE ITSELF sits farther
+than a tolerance from that run, no fp64 implementation can be held to the tolerance against it, and the bound becomes COND_FACTOR x the
+oracle's own distance from the exact iterate.  The arbiter is bounded and book-kept:
+  * every widening is a GRANT, recorded in GRANTS (printed in the pytest summary by conftest) and returned to the caller;
+  * a test states the CAP on what it lets the arbiter grant, per field (`cap={"K": 3e-5, ...}`); a field without a cap gets NO widening:
+    the plain tolerance applies even though `exact` was passed (its distance is still recorded);
+  * whatever the cap, a grant never exceeds HARD_CAP_REL x the field's scale;
+  * in full solves the long-double run must have taken the same decisions as the fp64 oracle (iteration / line-search / regularisation
+    counts, status): otherwise its iterates are not the oracle's exact counterparts and nothing is widened (compare_solve).
+"""
 import numpy as np
 
 STEP_FIELDS = {
@@ -25,14 +38,35 @@ def make_exact(pkg, ld_lib, phases, x0, **kw):
     return make_pair(pkg, ld_lib, ld_lib, phases, x0, **kw)[0]
 
 
-COND_FACTOR = 10.0     # rounding-error realisations of two fp64 implementations of one algebra scatter by about this much
+COND_FACTOR = 10.0     # rounding-error realisations of two fp64 implementations of one algebra scatter by about this much (checked against the
+#                        measured GPU / emulator distances in DESIGN.md section 5: the largest observed ratio |gpu - exact| / |oracle - exact| is 1.5 on K)
+HARD_CAP_REL = 1e-4    # no grant beyond this fraction of a field's scale, whatever a test's cap says
+GRANTS = []            # (tag, field, phase, plain tolerance, granted tolerance, oracle-vs-exact, measured error, scale): every widening of a session
 
 
-def compare(sa, sb, fields, nph, rtol, tag, atol_K=None, exact=None):
-    """sa: fp64 oracle, sb: backend under test.  Every field must agree to rtol x its scale (K: atol_K absolute, north_star's
-    1e-6).  `exact` (optional): the long-double oracle run through the same steps.  Where the problem is so badly conditioned that
-    the fp64 ORACLE ITSELF sits farther than the tolerance from the exact iterate, no fp64 implementation can meet the tolerance
-    against it; the bound is then COND_FACTOR x the oracle's own distance from the exact iterate (measured here, per field)."""
+def _cap_of(cap, f):
+    if cap is None:
+        return 0.0
+    if isinstance(cap, dict):
+        return float(cap.get(f, cap.get("*", 0.0)))
+    return float(cap)
+
+
+def arbitrate(tag, f, i, tol, own, sc, cap, err=None):
+    """Tolerance after arbitration.  own: the oracle's distance from the exact run; cap: the most this test lets the arbiter grant for f."""
+    want = COND_FACTOR * own
+    if want <= tol:
+        return tol
+    granted = min(want, _cap_of(cap, f), HARD_CAP_REL * sc)
+    if granted <= tol:
+        return tol
+    GRANTS.append((tag, f, i, tol, granted, own, err, sc))
+    print(f"[arbiter] {tag}: field {f} phase {i}: tolerance {tol:.3e} -> {granted:.3e} (oracle-vs-exact {own:.3e}, scale {sc:.3e}, cap {_cap_of(cap, f):.3e})")
+    return granted
+
+
+def compare(sa, sb, fields, nph, rtol, tag, atol_K=None, exact=None, cap=None):
+    """sa: fp64 oracle, sb: backend under test, exact: long-double oracle (optional).  Returns {(field, phase): (err, scale, own, tol)}."""
     worst = {}
     for f in fields:
         for i in range(nph):
@@ -45,66 +79,95 @@ def compare(sa, sb, fields, nph, rtol, tag, atol_K=None, exact=None):
                 tol = atol_K     # north_star: ||K_gpu - K_cpu||_inf < 1e-6 (absolute)
             own = None
             if exact is not None:
-                own = np.abs(a - exact.field(i, f)).max()
-                tol = max(tol, COND_FACTOR * own)
-            worst[(f, i)] = (err, sc, own)
+                own = float(np.abs(a - exact.field(i, f)).max())
+                tol = arbitrate(tag, f, i, tol, own, sc, cap, float(err))
+            worst[(f, i)] = (float(err), float(sc), own, float(tol))
             assert err <= tol, f"{tag}: field {f} phase {i}: |diff|={err:.3e} > {tol:.3e} (scale {sc:.3e}, oracle-vs-exact {own})"
     return worst
 
 
-def run_steps(pkg, sa, sb, phases, opt, n_iter=2, rtol=1e-8, atol_K=1e-6, exact=None, rtol_scalar=None):
+def granted_max(worst, plain_rtol, atol_K=None):
+    """Largest tolerance in a compare() result that exceeds the plain one, per field: what the arbiter granted."""
+    out = {}
+    for (f, i), (err, sc, own, tol) in worst.items():
+        plain = atol_K if (f == "K" and atol_K is not None) else plain_rtol * sc
+        if tol > plain:
+            out[f] = max(out.get(f, 0.0), tol)
+    return out
+
+
+def _scalar_tol(tag, name, plain, a, x, cap):
+    """Relative tolerance of a per-problem scalar after arbitration (a: oracle, x: exact or None)."""
+    if x is None:
+        return plain
+    own = float(np.max(np.abs(a - x) / np.maximum(np.abs(a), 1e-300)))
+    return arbitrate(tag, name, -1, plain, own, 1.0, cap)
+
+
+def run_steps(pkg, sa, sb, phases, opt, n_iter=2, rtol=1e-8, atol_K=1e-6, exact=None, rtol_scalar=None, cap=None):
     """Per-iterate parity: rollout -> LQ -> backward sweep -> linear rollout -> rollout(eps=1) ..."""
     nph = len(phases)
     every = (sa, sb) if exact is None else (sa, sb, exact)
+    report = {}
     for it in range(n_iter):
         eps = 0.0 if it == 0 else 1.0
         for s in every:
             s.hybrid_rollout(eps, opt); s.compute_cost(opt)
-        compare(sa, sb, STEP_FIELDS["rollout"], nph, rtol, f"rollout{it}", exact=exact)
+        report.update({(f"rollout{it}",) + k: v for k, v in compare(sa, sb, STEP_FIELDS["rollout"], nph, rtol, f"rollout{it}", exact=exact, cap=cap).items()})
         fa, fb = sa.measure_dynamics_feasibility(), sb.measure_dynamics_feasibility()
         rs = rtol_scalar if rtol_scalar is not None else max(1e-10, 1e-2 * rtol)     # scalars: 1e-10 at the default per-iterate tolerance
-        if exact is not None:
-            rs = max(rs, COND_FACTOR * float(np.max(np.abs(fa - exact.measure_dynamics_feasibility()) / np.maximum(np.abs(fa), 1e-300))))
+        rs = _scalar_tol(f"rollout{it}", "feas", rs, fa, exact.measure_dynamics_feasibility() if exact is not None else None, cap)
         assert np.allclose(fa, fb, rtol=rs, atol=1e-12), (fa, fb)
         ia, ib = sa.info_arrays(), sb.info_arrays()
         rc = rtol_scalar if rtol_scalar is not None else max(1e-10, 1e-2 * rtol)
-        if exact is not None:
-            ix = exact.info_arrays()
-            rc = max(rc, COND_FACTOR * float(np.max(np.abs(ia["actual_cost"] - ix["actual_cost"]) / np.maximum(np.abs(ia["actual_cost"]), 1e-300))))
+        rc = _scalar_tol(f"rollout{it}", "cost", rc, ia["actual_cost"], exact.info_arrays()["actual_cost"] if exact is not None else None, cap)
         assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=rc, atol=1e-10), (ia["actual_cost"], ib["actual_cost"])
         if it == 0:
             for s in every:
                 s.update_nominal_trajectory()
         for s in every:
             s.LQ_approximation(opt)
-        compare(sa, sb, STEP_FIELDS["lq"], nph, rtol, f"lq{it}", exact=exact)
+        report.update({(f"lq{it}",) + k: v for k, v in compare(sa, sb, STEP_FIELDS["lq"], nph, rtol, f"lq{it}", exact=exact, cap=cap).items()})
         oks = [s.backward_sweep(0.0) for s in every]
         assert np.array_equal(oks[0], oks[1]) and oks[0].all()
-        compare(sa, sb, STEP_FIELDS["sweep"], nph, rtol, f"sweep{it}", atol_K=atol_K, exact=exact)
+        report.update({(f"sweep{it}",) + k: v for k, v in compare(sa, sb, STEP_FIELDS["sweep"], nph, rtol, f"sweep{it}", atol_K=atol_K, exact=exact, cap=cap).items()})
 
         def dv_close(tag):
             da, db = sa.get_exp_cost_change(), sb.get_exp_cost_change()
+            dx = exact.get_exp_cost_change() if exact is not None else None
             for q in (0, 1):
-                r = 1e-8
-                if exact is not None:
-                    dx = exact.get_exp_cost_change()
-                    r = max(r, COND_FACTOR * float(np.max(np.abs(da[q] - dx[q]) / np.maximum(np.abs(da[q]), 1e-300))))
+                r = _scalar_tol(f"{tag}{it}", f"dV_{q + 1}", 1e-8, da[q], dx[q] if dx is not None else None, cap)
                 assert np.allclose(da[q], db[q], rtol=r, atol=1e-10), (tag, q, da[q], db[q])
         dv_close("sweep")
         for s in every:
             s.linear_rollout(1.0, opt)
-        compare(sa, sb, STEP_FIELDS["linear"], nph, rtol, f"linear{it}", exact=exact)
+        report.update({(f"linear{it}",) + k: v for k, v in compare(sa, sb, STEP_FIELDS["linear"], nph, rtol, f"linear{it}", exact=exact, cap=cap).items()})
         dv_close("linear")
+    return report
 
 
-def compare_solve(sa, sb, nph, rtol=1e-6, atol_K=1e-6, exact=None):
+SOLVE_FIELDS = ["XBAR", "UBAR", "X", "U", "Y", "K", "DU", "QU", "QUU", "QUX"]
+COUNT_KEYS = ("n_iters", "n_ls_iters", "n_reg_iters", "status")
+
+
+def compare_solve(sa, sb, nph, rtol=1e-6, atol_K=1e-6, exact=None, cap=None, tag="solve"):
+    """Full-solve parity.  Counts and status must be identical.  `exact` only arbitrates if the long-double run walked the same control
+    flow as the fp64 oracle (same counts, same status) on every problem; otherwise the plain tolerances apply."""
     ia, ib = sa.info_arrays(), sb.info_arrays()
-    for k in ("n_iters", "n_ls_iters", "n_reg_iters", "status"):
+    for k in COUNT_KEYS:
         assert np.array_equal(ia[k], ib[k]), (k, ia[k], ib[k])
-    ix = exact.info_arrays() if exact is not None else None
+    ix = None
+    if exact is not None:
+        ix = exact.info_arrays()
+        same_flow = all(np.array_equal(ia[k], ix[k]) for k in COUNT_KEYS)
+        if not same_flow:
+            print(f"[arbiter] {tag}: the long-double run took other decisions than the fp64 oracle "
+                  f"({ {k: (ia[k].tolist(), ix[k].tolist()) for k in COUNT_KEYS if not np.array_equal(ia[k], ix[k])} }): no arbitration, plain tolerances")
+            exact, ix = None, None
     for k in ("actual_cost", "dyn_feas", "max_tconstr", "max_pconstr"):
-        r, at = rtol, 1e-8
+        at = 1e-8
         if ix is not None:
-            own = np.abs(ia[k] - ix[k]); at = max(at, COND_FACTOR * float(own.max()))
-        assert np.allclose(ia[k], ib[k], rtol=r, atol=at), (k, ia[k], ib[k])
-    return compare(sa, sb, ["XBAR", "UBAR", "X", "U", "Y", "K", "DU", "QU", "QUU", "QUX"], nph, rtol, "solve", atol_K=atol_K, exact=exact)
+            own = float(np.abs(ia[k] - ix[k]).max())
+            at = arbitrate(tag, k, -1, at, own, max(1.0, float(np.abs(ia[k]).max())), cap)
+        assert np.allclose(ia[k], ib[k], rtol=rtol, atol=at), (k, ia[k], ib[k])
+    return compare(sa, sb, SOLVE_FIELDS, nph, rtol, tag, atol_K=atol_K, exact=exact, cap=cap)

@@ -93,4 +93,6 @@ def test_cpp_host_mirror_runs_end_to_end(oracle_lib, tmp_path):
     assert out["cost"] == ia["actual_cost"][0] and out["feas"] == ia["dyn_feas"][0]
     assert np.array_equal(np.array(out["ubar0"]), s.field(0, "UBAR")[0].ravel())
     hst = s.get_history(0)
-    assert np.array_equal(np.array(out["history_cost"], dtype=np.float32), hst["cost"]) and len(hst["cost"]) == out["n_iters"] + 1 or len(hst["cost"]) >= 2
+    assert np.array_equal(np.array(out["history_cost"], dtype=np.float32), hst["cost"])
+    # one entry after the initial rollout + one per inner iteration that ran to its last line (MultiPhaseDDP.cpp:258-261, 382-385): at most n_iters + 1
+    assert 2 <= len(hst["cost"]) <= out["n_iters"] + 1

@@ -2,7 +2,9 @@
 
 Tolerances (fp64): every trajectory field relative 1e-8 of its scale per iterate; feedback gains
 ||K_gpu - K_cpu||_inf < 1e-6 absolute (BASELINE.json north_star); iteration / line-search / regularisation
-counts identical.
+counts identical.  The long-double arbiter (parity_common, `exact=`) is passed ONLY to the conditioning-limited cases, each with a cap per field on
+what it may grant (measured by tools/arbiter_survey.py on the CPU, rounded up by about two): the barrel roll (per iterate, full solve, config 4)
+and single shooting through the single-rigid-body tail.  Every other test holds the plain tolerances.
 """
 import json
 import os
@@ -14,6 +16,16 @@ from conftest import pkg, ROOT
 import parity_common as pc
 
 pytestmark = pytest.mark.gpu
+
+# Caps on what the long-double arbiter may grant, per field (absolute; scalars: relative for the per-iterate driver, absolute in compare_solve).
+# Measured: tools/arbiter_survey.py (the fp64 oracle against its long-double build, CPU), worst grant per field x ~2.  A field that is not
+# listed gets no widening; a test without `exact=` holds the plain tolerances (1e-8 x scale per iterate, 1e-6 x scale per solve, K 1e-6 absolute).
+CAP_BARREL_ITERATE = {"K": 2e-4, "DU": 6e-5, "DX": 2e-4, "G": 5e-4, "H0": 1e-1, "QU": 5e-3, "QUU": 1.5e-2, "QUX": 3e-2, "dV_1": 5e-8, "dV_2": 1e-7}   # second iterate, |K| = 659, |H0| = 7.7e6
+CAP_BARREL_SOLVE = {"K": 3e-5, "actual_cost": 1e-3, "dyn_feas": 2e-7}                 # shipped barrel roll, |K| = 74, cost ~ 4e3
+CAP_CONFIG4 = {"actual_cost": 1e-7}
+CAP_SS_MHPC_STEP = {"K": 6e-5, "QU": 2e-7, "G": 4e-5, "X": 3e-3, "XSIM": 3e-3, "U": 7e-3, "L": 9e-2, "PHI": 60.0}      # |K| = 4e4, |X| = 5e4 after a half step, |PHI| = 1.7e9
+CAP_SS_MHPC_SOLVE = {"XBAR": 4e-2, "X": 4e-2, "UBAR": 7e-2, "U": 7e-2, "Y": 3e-4, "K": 5e-2, "DU": 9e-3, "QU": 4e-3, "QUU": 4e-6, "QUX": 3e-2,
+                     "actual_cost": 10.0, "max_pconstr": 3e-4}                         # |K| = 6.9e3, |UBAR| = 1e3, cost 5e4
 
 
 def test_backend_is_hip(hip_lib):
@@ -52,7 +64,8 @@ def test_per_iterate_parity(hip_lib, oracle_lib, oracle_ld_lib, which):
         # gains reach |K| ~ 650 on the second iterate and the fp64 oracle itself sits ~1e-5 from the exact (long-double) gains there:
         # north_star's 1e-6 holds wherever the oracle's own distance from the exact iterate allows it, the long-double run arbitrates
         # the rest (parity_common.compare; measured bounds in DESIGN.md section 5)
-        pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, exact=pc.make_exact(pkg, oracle_ld_lib, phases, x0), rtol_scalar=1e-8)
+        rep = pc.run_steps(pkg, so, sg, phases, pkg.problems.br_ddp_setting(), n_iter=2, exact=pc.make_exact(pkg, oracle_ld_lib, phases, x0), rtol_scalar=1e-8, cap=CAP_BARREL_ITERATE)
+        assert not any(k[0].endswith("0") and v[3] > (1e-6 if k[1] == "K" else 1e-8 * v[1]) for k, v in rep.items())      # the first iterate needs no arbitration at all
         return
     if which == "hkd":         # HKD-MPC trot (24/24/0): kinodynamic phases with lift-off / touchdown reset maps
         phases = pkg.problems.hkd_trot_problem(horizons=(6, 7, 6, 5))
@@ -104,7 +117,7 @@ def test_full_solve_parity_hkd(hip_lib, oracle_lib):
 
 
 @pytest.mark.parametrize("gait", ["bound", "trot/dynfeas"])
-def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, oracle_ld_lib, gait):
+def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, gait):
     """The MHPC problem as MHPCProblem::initialization builds it from a shipped gait file + the shipped settings
     (cafe_mpc_amd.builder over tests/golden/cafe_tree): whole-body phases from the gait's contact changes, SRB tail, ddp_setting.info."""
     import importlib, os
@@ -115,15 +128,14 @@ def test_full_solve_parity_shipped_gaits(hip_lib, oracle_lib, oracle_ld_lib, gai
     opt = builder.load_ddp_setting(os.path.join(tree, "MHPC/settings/ddp_setting.info"))
     x0 = np.vstack([info["x0"], info["x0"] + 0.01 * (pkg.problems.wb_ensemble_x0(2, 3) - pkg.problems.wb_nominal_state())])
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
-    so.solve(opt); sg.solve(opt); sx.solve(opt)
-    pc.compare_solve(so, sg, len(phases), exact=sx)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
     assert (sg.info_arrays()["status"] == 0).all()
     cmd = sg.export_mpc_command(problem=0, n_steps=8, mpc_time=0.0, dt=cfg["dt_wb"], status_times=info["status_durations"][:len(phases)] if False else None)
     assert cmd["N_mpcsteps"] == 8 and np.isfinite(cmd["feedback"]).all()
 
 
-def test_full_solve_parity_hkd_shipped_gait(hip_lib, oracle_lib, oracle_ld_lib):
+def test_full_solve_parity_hkd_shipped_gait(hip_lib, oracle_lib):
     """HKD-MPC problem as HKDProblem::initialization builds it from the bound gait (HKDMPC.h:30) with HKDMPC/settings: 7 phases / 60 knots."""
     import importlib, os
     from conftest import ROOT
@@ -135,14 +147,13 @@ def test_full_solve_parity_hkd_shipped_gait(hip_lib, oracle_lib, oracle_ld_lib):
     opt.max_AL_iter, opt.max_DDP_iter = 2, 4
     x0 = np.vstack([info["x0"], info["x0"]]); x0[1, :12] += 0.01
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
-    so.solve(opt); sg.solve(opt); sx.solve(opt)
-    pc.compare_solve(so, sg, len(phases), exact=sx)
+    so.solve(opt); sg.solve(opt)
+    pc.compare_solve(so, sg, len(phases))
     pf_o, pf_g = builder.hkd_next_footholds(so, info["contacts"]), builder.hkd_next_footholds(sg, info["contacts"])
     assert set(pf_g) == set(pf_o) and all(np.allclose(pf_g[l], pf_o[l], atol=1e-6) for l in pf_g)
 
 
-def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
+def test_receding_horizon_loop_parity(hip_lib, oracle_lib):
     """The MPC loop of testTrajOptInLoop.cpp:85-117 in shape: solve, then per tick MHPCProblem::update (phase table shift incl. the young
     single-shooting phases) moved INSIDE the handle (hsddp_reconfigure: trajectories, ReB / AL parameters, solver counters carried; no
     device allocation once the handle is warm), runtime iteration limits.  GPU and oracle run the same loop, every tick's solve must agree;
@@ -160,10 +171,9 @@ def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
     phases, info = pd.describe(ubar_mode="gravity_comp")
     x0 = np.vstack([info["x0"], info["x0"] + 0.005 * (pkg.problems.wb_ensemble_x0(1, 3)[0] - pkg.problems.wb_nominal_state())])
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
-    for s_ in (so, sg, sx):
+    for s_ in (so, sg):
         s_.solve(opt0)
-    pc.compare_solve(so, sg, len(phases), exact=sx)
+    pc.compare_solve(so, sg, len(phases))
     seen_young = False
     mallocs = []
     for tick in range(1, 9):
@@ -174,8 +184,7 @@ def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
         if tick == 2:                   # the two-handle route on the GPU, for comparison with the in-place one below
             s2, ph2, _ = builder.shift_solver(pkg.Solver, hip_lib, sg, phases, pd, m)
         old_phases = phases
-        for s_ in (so, sx):
-            builder.shift_solver_in_place(s_, old_phases, pd, m)
+        builder.shift_solver_in_place(so, old_phases, pd, m)
         phases, inf2 = builder.shift_solver_in_place(sg, old_phases, pd, m)
         if tick == 2:
             for i in range(len(phases)):
@@ -183,9 +192,9 @@ def test_receding_horizon_loop_parity(hip_lib, oracle_lib, oracle_ld_lib):
                     assert np.array_equal(s2.field(i, f), sg.field(i, f)), (i, f)
             s2.close()
         seen_young |= 0 in inf2["shooting"]
-        for s_ in (so, sg, sx):
+        for s_ in (so, sg):
             s_.set_initial_condition(x0n); s_.solve(opt_rt)
-        pc.compare_solve(so, sg, len(phases), exact=sx)
+        pc.compare_solve(so, sg, len(phases))
         assert sum(inf2["horizons"]) == 25
         mallocs.append(hip_lib.hsddp_debug_malloc_count())
     assert seen_young
@@ -204,7 +213,8 @@ def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib, oracle_ld_lib):
     so.solve(opt); sg.solve(opt); sx.solve(opt)
     # a 125-knot zero-torque start amplifies rounding differences: control flow exactly, every field (gains included) to north_star's
     # tolerance or, where the fp64 oracle itself is farther than that from the long-double iterate, to the arbitrated bound
-    pc.compare_solve(so, sg, len(phases), exact=sx)
+    w = pc.compare_solve(so, sg, len(phases), exact=sx, cap=CAP_BARREL_SOLVE, tag="barrel_roll_full")
+    assert set(pc.granted_max(w, 1e-6, 1e-6)) <= {"K"}, pc.granted_max(w, 1e-6, 1e-6)      # the gains are the only trajectory field that needs the arbiter here
 
 
 def test_full_solve_fixed_work_mode(hip_lib, oracle_lib):
@@ -233,17 +243,16 @@ def test_fixed_work_past_convergence_line_search_counts(hip_lib, oracle_lib):
     pc.compare_solve(so, sg, len(phases))
 
 
-def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib, oracle_ld_lib):
+def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib):
     """Ubar = 0 (testMHPCProblem.cpp:70-76): hard start that exercises multi-trial line searches and rejected steps."""
     phases = pkg.problems.wb_stance_problem(horizon=50, ubar_mode="zero")     # BASELINE config 1 literal
     x0 = np.vstack([pkg.problems.wb_nominal_state()[None], pkg.problems.wb_ensemble_x0(2, 7)])
     opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=1)
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
-    so.solve(opt); sg.solve(opt); sx.solve(opt)
+    so.solve(opt); sg.solve(opt)
     ia, ib = so.info_arrays(), sg.info_arrays()
     assert np.array_equal(ia["n_ls_iters"], ib["n_ls_iters"]) and (ia["n_ls_iters"] > ia["n_iters"]).any()
-    pc.compare_solve(so, sg, 1, exact=sx)
+    pc.compare_solve(so, sg, 1)
 
 
 def test_batch_independence_and_full_size_properties(hip_lib):
@@ -376,7 +385,8 @@ def test_config4_barrel_roll_running_schedule(hip_lib, oracle_lib, oracle_ld_lib
     so = pc.make_pair(pkg, oracle_lib, oracle_lib, phases, xs)[0]
     sx = pc.make_exact(pkg, oracle_ld_lib, phases, xs)
     so.solve(opt); sx.solve(opt)
-    pc.compare_solve(so, _Sub(s, idx), len(phases), exact=sx)
+    w = pc.compare_solve(so, _Sub(s, idx), len(phases), exact=sx, cap=CAP_CONFIG4, tag="config4")
+    assert not pc.granted_max(w, 1e-6, 1e-6)      # every trajectory field, the gains included, at the plain tolerances (only the cost scalar is arbitrated)
 
 
 def test_cpp_host_mirror_against_the_hip_library(hip_lib, tmp_path):
@@ -439,21 +449,27 @@ def test_single_shooting_solve_parity(hip_lib, oracle_lib, oracle_ld_lib, which)
         x0 = pkg.problems.wb_ensemble_x0(3, 20241227)
         opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=3, MS=0)
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)      # (the single-rigid-body gains reach |K| ~ 4e4: the long-double run arbitrates the absolute 1e-6 there)
-    for s_ in (so, sg, sx):       # per-iterate first: rollout of the nominal, LQ, sweep, rollout of a full step
+    # the single-rigid-body tail under single shooting is the one badly conditioned gait case (gains reach |K| ~ 4e4 and the states run through
+    # them knot after knot): the long-double run arbitrates there, with caps; the whole-body trot and the kinodynamic problem hold the plain tolerances
+    arb = which == "mhpc"
+    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0) if arb else None
+    every = (so, sg, sx) if arb else (so, sg)
+    for s_ in every:       # per-iterate first: rollout of the nominal, LQ, sweep, rollout of a full step
         s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.update_nominal_trajectory(); s_.LQ_approximation(opt)
         assert s_.backward_sweep(0.0).all()
-    pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, "ss0", atol_K=1e-6, exact=sx)
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"] + pc.STEP_FIELDS["lq"] + pc.STEP_FIELDS["sweep"], len(phases), 1e-8, f"ss0[{which}]", atol_K=1e-6, exact=sx, cap=CAP_SS_MHPC_STEP)
     assert np.abs(sg.field(0, "DEFECT")).max() == 0.0
-    for s_ in (so, sg, sx):
+    for s_ in every:
         s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
     # a single-shooting rollout through gains of 4e4 amplifies the rounding of the states: the long-double run bounds what fp64 can agree on
-    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1", exact=sx)
-    so.close(); sg.close(); sx.close()
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, f"ss1[{which}]", exact=sx, cap=CAP_SS_MHPC_STEP)
+    for s_ in every:
+        s_.close()
     so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
-    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0)
-    so.solve(opt); sg.solve(opt); sx.solve(opt)
-    pc.compare_solve(so, sg, len(phases), exact=sx)
+    sx = pc.make_exact(pkg, oracle_ld_lib, phases, x0) if arb else None
+    for s_ in ((so, sg, sx) if arb else (so, sg)):
+        s_.solve(opt)
+    pc.compare_solve(so, sg, len(phases), exact=sx, cap=CAP_SS_MHPC_SOLVE, tag=f"ss_solve[{which}]")
     assert (sg.info_arrays()["n_iters"] >= 2).all()
 
 

@@ -53,7 +53,8 @@ def test_kernel_programs_match_oracle(emu_lib, oracle_lib, oracle_ld_lib, which)
     # the barrel-roll iterate after a full step from the zero-torque start is badly conditioned: the fp64 oracle itself sits ~1e-5 from
     # the exact (long-double) gains at |K| ~ 650, so the long-double run arbitrates there (parity_common.compare)
     exact = pc.make_exact(pkg, oracle_ld_lib, phases, x0) if which == "barrel_roll" else None
-    pc.run_steps(pkg, so, se, phases, opt, n_iter=2, rtol=1e-8, exact=exact, rtol_scalar=1e-8 if exact is not None else None)
+    pc.run_steps(pkg, so, se, phases, opt, n_iter=2, rtol=1e-8, exact=exact, rtol_scalar=1e-8 if exact is not None else None,
+                 cap={"K": 1.5e-5, "DU": 1.2e-5, "QU": 2e-4, "G": 3e-3, "H0": 8e-5, "DX": 3e-5})      # measured grants of this iterate x 2 (|K| = 646, |G| = 1.2e5)
 
 
 def test_one_wave_lq_variant_matches_oracle(oracle_lib):
