@@ -16,6 +16,7 @@
 #include "hs_types.hpp"
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
+#include "wb_quad.hpp"
 #include "srb_knot.hpp"
 #include "hkd_knot.hpp"
 #include "sweep.hpp"
@@ -88,18 +89,21 @@ struct EpsList { double e[MAXCAND]; int n, writer, from_state; };
 // LDS of the kernels instantiated WITHOUT the whole-body model (kinodynamic / single-rigid-body handles): 8 KB instead of 16 / 40 KB, so that
 // their small knots are not held to the whole-body kernels' two waves per SIMD
 union RedLds { HkdLds h; SrbLds s; };
+// slot_list / nlist: the slots this launch covers (null: all nslots) - when the lane-quad kernel takes the whole-body running knots of a launch,
+// the one-wave programs only see the rest (terminal knots with their reset maps, single-rigid-body knots); unit_knots: running knots among them
 #define ROLL_ARGS const PhaseDev* ph_, int nph, const int* slot_phase, const int* slot_k, int nslots, int batch, ModelDev md, EpsList el, OptDev opt, const double* x0, SlotArrays sa, \
-                  const ProbState* st, int mask, int* fail, unsigned long long* units
+                  const ProbState* st, int mask, int* fail, unsigned long long* units, const int* slot_list, int nlist, int unit_knots
 template <bool WBM, class LDS> __device__ __forceinline__ void rollout_body(LDS& L, ROLL_ARGS) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
-    const int per = batch * nslots;
+    const int per = batch * nlist;
     const int c = blockIdx.x / per, r = blockIdx.x - c * per;
-    const int b = r / nslots, s = r - b * nslots;
+    const int b = r / nlist, si = r - b * nlist;
     if (masked_out(st[b], mask)) return;
-    if (s == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)nslots - nph);     // knots this launch rolls out (measurement only)
+    if (si == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)unit_knots);     // knots this launch rolls out (measurement only)
+    const int s = slot_list != nullptr ? slot_list[si] : si;
     const int pi = slot_phase[s], k = slot_k[s];
     PhaseC& P = ph[pi];
-    const size_t cbase = (size_t)c * per;                       // slice of candidate c in the slot arrays
+    const size_t cbase = (size_t)c * batch * nslots;            // slice of candidate c in the slot arrays
     SlotOut so{sa.cost, sa.dsq, sa.ming, sa.maxh};
     const size_t slot_base = cbase + (size_t)b * nslots, slot = slot_base + s;
     const double eps = el.from_state ? st[b].ls_eps : el.e[c];
@@ -132,7 +136,7 @@ template <bool WBM, class LDS> __device__ __forceinline__ void rollout_body(LDS&
     // single-shooting phases from here on (young phases behind a terminal knot, or the whole horizon): ONE call site, one copy of the code
     if (chain_first >= 0 && chain_first < nph && !ph[chain_first].shooting) rollout_chain<WBM>(L, ph, nph, chain_first, md, b, nslots, eps, opt, so, slot_base, fail, wr);
 }
-#define ROLL_PASS ph_, nph, slot_phase, slot_k, nslots, batch, md, el, opt, x0, sa, st, mask, fail, units
+#define ROLL_PASS ph_, nph, slot_phase, slot_k, nslots, batch, md, el, opt, x0, sa, st, mask, fail, units, slot_list, nlist, unit_knots
 __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(ROLL_ARGS) { __shared__ WbCore L; rollout_body<true>(L, ROLL_PASS); }
 // handles without whole-body phases (has_hkd): no whole-body code, 8 KB of LDS, no register cap
 // (measured on config 5, waves per SIMD rollout / LQ: none/none 111.6 k it/s, 3/- 117.7 k, 4/- 121.9 k, 4/5 122.1 k, 5/5 122.5 k; 8 KB of LDS allow five)
@@ -145,6 +149,36 @@ __global__ void __launch_bounds__(64) ROLL_ATTR k_rollout(ROLL_ARGS) { __shared_
 #define ROLL_HKD_ATTR
 #endif
 __global__ void __launch_bounds__(64) ROLL_HKD_ATTR k_rollout_hkd(ROLL_ARGS) { __shared__ RedLds L; rollout_body<false>(L, ROLL_PASS); }
+
+// The whole-body running knots of the phases with shooting nodes on LANE QUADS (wb_quad.hpp): one lane per leg, sixteen problems of the same
+// (candidate, knot) per wave.  grid = candidates x knots of the list x ceil(batch / 16); qslots: the slots this kernel owns.
+#ifndef QUAD_WPE
+#define QUAD_WPE 1      // waves per SIMD the quad kernel is compiled for (1: up to 512 registers, nothing in scratch; 2: 256 registers)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QUAD_WPE, QUAD_WPE)))
+k_rollout_quad(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, const int* qslots, int nq, int nslots, int batch, ModelDev md, EpsList el, OptDev opt, const double* x0,
+               SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
+    PhaseC* ph = (PhaseC*)ph_;
+    const int nbg = (batch + 15) >> 4;
+    const int per = nq * nbg;
+    const int c = blockIdx.x / per, r = blockIdx.x - c * per;
+    const int qi = r / nbg, bg = r - qi * nbg;
+    const int s = qslots[qi], pi = slot_phase[s], k = slot_k[s];
+    const int b = bg * 16 + (threadIdx.x >> 2);
+    const bool active = b < batch && !masked_out(st[b < batch ? b : 0], mask);
+    {   // knots this launch rolls out (measurement only): one atomic per wave
+        const unsigned long long m = __ballot(active && (threadIdx.x & 3) == 0);
+        if (threadIdx.x == 0 && m != 0) atomicAdd(units, (unsigned long long)__popcll(m));
+    }
+    if (!active) return;      // (a quad leaves or stays as a whole: the cross-lane steps below need all four lanes)
+    const double eps = el.from_state ? st[b].ls_eps : el.e[c];
+    const QuadOut q = wbq_rollout_knot<QD>(ph[pi], md, b, k, eps, opt.ReB_active, pi == 0 ? x0 : nullptr, c == el.writer);
+    if ((threadIdx.x & 3) == 0) {
+        const size_t slot = ((size_t)c * batch + b) * nslots + s;
+        sa.cost[slot] = q.cost; sa.dsq[slot] = q.dsq; sa.ming[slot] = q.ming; sa.maxh[slot] = 0.0;
+        if (q.bad) fail[(size_t)c * batch + b] = 1;
+    }
+}
 
 // Batched line search, decision step (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:108-131, for the candidates of one probe launch): per
 // problem the candidates are examined IN ORDER - reduction of the slice's partials, merit, Armijo test - exactly as if they had been
@@ -529,6 +563,8 @@ struct hsddp_handle {
     PhaseDev* d_ph = nullptr;
     PhaseDev* d_ph_ss = nullptr;      // the same descriptors with every shooting flag cleared: what option.MS = false rolls out (MultiPhaseDDP.cpp:65-68)
     int *d_slot_phase = nullptr, *d_slot_k = nullptr, *d_fail = nullptr, *d_do_update = nullptr, *d_counters = nullptr, *d_success = nullptr;
+    int *d_qslots = nullptr, *d_oslots = nullptr; int nq = 0, n_other = 0, other_knots = 0;      // slots of the lane-quad kernel (whole-body running knots of phases with shooting nodes) / the rest
+    bool quad = true;                 // the lane-quad kernel takes its slots of every multiple-shooting rollout launch (HSDDP_QUAD=0: the one-wave programs everywhere)
     int* h_counters = nullptr;        // pinned
     SlotArrays sp{}; int sp_cands = 0;       // slot partials of the candidates of a batched line-search launch: [sp_cands][batch][nslots] (allocated on first use)
     bool probe_ok = true;                    // every phase without shooting nodes is a whole-body phase (their chain keeps its state in LDS: probes need no trajectory store)
@@ -589,6 +625,17 @@ static hipError_t dev_replicate(void* base, size_t one, size_t count) {
         have += n;
     }
     return hipSuccess;
+}
+
+// slots of a window by rollout program: the lane-quad kernel owns the running knots of whole-body phases with shooting nodes, the one-wave
+// programs everything else (terminal knots and their reset maps, single-rigid-body / kinodynamic knots, phases without shooting nodes)
+static void split_slots(const std::vector<PhaseDev>& ph, const std::vector<int>& sp, const std::vector<int>& sk, std::vector<int>& qs, std::vector<int>& os, int& other_knots) {
+    qs.clear(); os.clear(); other_knots = 0;
+    for (size_t s = 0; s < sp.size(); s++) {
+        const PhaseDev& P = ph[sp[s]];
+        if (P.model == HSDDP_MODEL_WB && P.shooting && sk[s] < P.h) qs.push_back((int)s);
+        else { os.push_back((int)s); if (sk[s] < P.h) other_knots++; }
+    }
 }
 
 static OptDev to_dev(const hsddp_option_t& o) {
@@ -668,6 +715,7 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
     h->slots_cap = h->nslots + 16; h->nph_cap = n_phases + 8;      // slack: a receding-horizon update adds or drops a phase (one slot) now and then
     if (!rc) rc |= dalloc(h, &h->d_ph, h->nph_cap); if (!rc) rc |= dalloc(h, &h->d_ph_ss, h->nph_cap);
     if (!rc) rc |= dalloc(h, &h->d_slot_phase, h->slots_cap); if (!rc) rc |= dalloc(h, &h->d_slot_k, h->slots_cap);
+    if (!rc) rc |= dalloc(h, &h->d_qslots, h->slots_cap); if (!rc) rc |= dalloc(h, &h->d_oslots, h->slots_cap);
     if (!rc) rc |= dalloc(h, &h->d_fail, B * MAXCAND); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
     if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n); if (!rc) rc |= dalloc(h, &h->d_units, 8);
     if (!rc) rc |= dalloc(h, &h->sa.cost, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * h->slots_cap);
@@ -680,6 +728,13 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
     CREATE_CK(hipMemcpy(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice));
     CREATE_CK(hipMemcpy(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
     CREATE_CK(hipMemcpy(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<int> qs, os; split_slots(h->ph, sp, sk, qs, os, h->other_knots);
+        h->nq = (int)qs.size(); h->n_other = (int)os.size();
+        if (h->nq) CREATE_CK(hipMemcpy(h->d_qslots, qs.data(), qs.size() * 4, hipMemcpyHostToDevice));
+        if (h->n_other) CREATE_CK(hipMemcpy(h->d_oslots, os.data(), os.size() * 4, hipMemcpyHostToDevice));
+        const char* e = getenv("HSDDP_QUAD"); h->quad = !(e && e[0] == '0');
+    }
     CREATE_CK(hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int)));
     CREATE_CK(hipDeviceSynchronize());
 #undef CREATE_CK
@@ -765,6 +820,10 @@ int hsddp_reconfigure(hsddp_handle_t* h, int n_phases, const hsddp_phase_desc_t*
         HIPCK(hipMemcpyAsync(h->d_ph_ss, ss.data(), sizeof(PhaseDev) * n_phases, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipMemcpyAsync(h->d_slot_phase, sp.data(), sp.size() * 4, hipMemcpyHostToDevice, h->stream));
         HIPCK(hipMemcpyAsync(h->d_slot_k, sk.data(), sk.size() * 4, hipMemcpyHostToDevice, h->stream));
+        std::vector<int> qs, os; int other_knots = 0; split_slots(np, sp, sk, qs, os, other_knots);
+        if (!qs.empty()) HIPCK(hipMemcpyAsync(h->d_qslots, qs.data(), qs.size() * 4, hipMemcpyHostToDevice, h->stream));
+        if (!os.empty()) HIPCK(hipMemcpyAsync(h->d_oslots, os.data(), os.size() * 4, hipMemcpyHostToDevice, h->stream));
+        h->nq = (int)qs.size(); h->n_other = (int)os.size(); h->other_knots = other_knots;
         HIPCK(hipStreamSynchronize(h->stream));      // (the host vectors above are the copy sources; the old window is no longer read after this point)
         // 4. the new window becomes the handle's
         if (!h->gen_allocs.empty()) { for (void* p : h->gen_allocs) hipFree(p); h->gen_allocs.clear(); }      // storage of hsddp_create: first tick only
@@ -811,8 +870,17 @@ static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}
 static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotArrays& sa, const OptDev& o, int mask, const char* name, int unit = UNIT_ROLLOUT) {
     Timed t(h, name);
     hipMemsetAsync(h->d_fail, 0, (size_t)h->batch * el.n * sizeof(int), h->stream);
+    if (h->quad && o.MS && h->nq > 0) {      // whole-body running knots on lane quads, the rest (terminal knots, single-rigid-body tail) on the one-wave programs
+        const int nbg = (h->batch + 15) / 16;
+        hipLaunchKernelGGL(k_rollout_quad, dim3((unsigned)((size_t)el.n * h->nq * nbg)), dim3(64), 0, h->stream, h->d_ph, h->d_slot_phase, h->d_slot_k, h->d_qslots, h->nq, h->nslots, h->batch,
+                           h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit);
+        if (h->n_other > 0)
+            hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->n_other)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k,
+                               h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit, h->d_oslots, h->n_other, h->other_knots);
+        return;
+    }
     hipLaunchKernelGGL(h->has_hkd ? k_rollout_hkd : k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k,
-                       h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit);
+                       h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit, (const int*)nullptr, h->nslots, h->nslots - h->nph);
 }
 static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask, bool eps_from_state = false) {
     EpsList el{}; el.e[0] = eps; el.n = 1; el.writer = 0; el.from_state = eps_from_state ? 1 : 0;

@@ -16,6 +16,7 @@
 #include "hs_types.hpp"
 #include "hs_host.hpp"
 #include "wb_knot.hpp"
+#include "wb_quad.hpp"
 #include "srb_knot.hpp"
 #include "hkd_knot.hpp"
 #include "sweep.hpp"
@@ -71,6 +72,7 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     memset(P.K, 0, (size_t)h->batch * P.h * P.m * P.n * 8); memset(P.dU, 0, h->batch * su * 8); memset(P.dX, 0, h->batch * sx * 8);
     return 0;
 }
+static bool emu_quad() { const char* e = getenv("HSDDP_EMU_QUAD"); return e && e[0] == '1'; }
 static OptDev to_dev(const hsddp_option_t& o) { OptDev d{}; d.AL_active = o.AL_active; d.ReB_active = o.ReB_active; d.MS = o.MS; return d; }
 // mirrors rollout_chain / k_rollout of cafe-mpc_amd/csrc/hsddp_hip.hip (the emulator cannot include the .hip file: it has no HIP runtime)
 static void emu_chain(hsddp_handle* h, const std::vector<PhaseDev>& ph, WbCore& L, int first, int b, double eps, const OptDev& o, SlotOut so) {
@@ -115,6 +117,9 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
                 SrbLds& Ls = *reinterpret_cast<SrbLds*>(&L);
                 if (k < P.h) srb_rollout_knot<64>(Ls, P, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
                 else { srb_rollout_terminal<64>(Ls, P, Pn, b, eps, so, slot); emu_chain(h, ph, L, pi + 1, b, eps, o, so); }
+            } else if (k < P.h && emu_quad()) {      // HSDDP_EMU_QUAD=1: the lane-quad program (wb_quad.hpp) in place of the one-wave knot, trajectories and contact-solve cache written
+                const QuadOut q = wbq_rollout_knot<QH>(P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, true);
+                so.cost[slot] = q.cost; so.dsq[slot] = q.dsq; so.ming[slot] = q.ming; so.maxh[slot] = 0.0; if (q.bad) h->fail[b] = 1;
             } else if (k < P.h) wb_rollout_knot<64>(L, P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, so, slot, h->fail.data());
             else { wb_rollout_terminal<64>(L, P, Pn, h->md, b, eps, o.AL_active, so, slot); emu_chain(h, ph, L, pi + 1, b, eps, o, so); }
         }
@@ -122,6 +127,22 @@ int hsddp_hybrid_rollout(hsddp_handle_t* h, double eps, const hsddp_option_t* op
         h->acost[b] = c; h->feas[b] = sqrt(d);
     }
     h->cache_valid = true;
+    return 0;
+}
+// per-slot merit partials of the last rollout [batch][nslots][3] = cost, defect^2, min g (tests compare the two rollout programs slot by slot)
+int hsddp_debug_slot_partials(hsddp_handle_t* h, double* out) {
+    for (size_t i = 0; i < (size_t)h->batch * h->nslots; i++) { out[3 * i] = h->cost[i]; out[3 * i + 1] = h->dsq[i]; out[3 * i + 2] = h->ming[i]; }
+    return 0;
+}
+// the lane-quad program as a PROBE of step eps (nothing written): its partials for every whole-body running knot, NaN elsewhere
+int hsddp_debug_quad_probe(hsddp_handle_t* h, double eps, const hsddp_option_t* opt, double* out) {
+    OptDev o = to_dev(*opt);
+    for (int b = 0; b < h->batch; b++) for (int s = 0; s < h->nslots; s++) {
+        const int pi = h->sp[s], k = h->sk[s]; const PhaseDev& P = h->ph[pi]; double* q3 = out + 3 * ((size_t)b * h->nslots + s);
+        if (P.model != HSDDP_MODEL_WB || !P.shooting || k == P.h) { q3[0] = q3[1] = q3[2] = NAN; continue; }
+        const QuadOut q = wbq_rollout_knot<QH>(P, h->md, b, k, eps, o.ReB_active, pi == 0 ? h->x0.data() : nullptr, false);
+        q3[0] = q.cost; q3[1] = q.dsq; q3[2] = q.ming;
+    }
     return 0;
 }
 int hsddp_compute_cost(hsddp_handle_t*, const hsddp_option_t*) { return 0; }

@@ -658,3 +658,26 @@ def test_unsupported_configurations_fail_loudly(hip_lib):
     mixed[-1]["desc"].model = pkg.MODEL_HKD          # SRB -> HKD: the reference has no such reset map
     with pytest.raises(RuntimeError):
         pkg.Solver(hip_lib, mixed, batch=1)
+
+
+def test_quad_and_one_wave_rollout_programs_agree(hip_lib, monkeypatch):
+    """The two rollout programs of the whole-body running knots on the device - lane quads (wb_quad.hpp, the default) and the one-wave knot
+    (HSDDP_QUAD=0) - through the same full solves: identical iteration / line-search counts, trajectories and gains to rounding level
+    (both are held to the oracle by every other test; this one pins them to each other, incl. the batched line search and the cache hand-over)."""
+    phases = pkg.problems.wb_trot_problem(horizons=(20, 20, 20, 20))
+    x0 = pkg.problems.wb_ensemble_x0(37, 20241220 + 3)         # (not a multiple of 16: a partly filled wave)
+    opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=8, cost_thresh=0.0)
+    sols = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HSDDP_QUAD", flag)
+        s = pkg.MultiPhaseDDP(phases, batch=x0.shape[0]); s.set_initial_condition(x0); s.solve(opt); sols.append(s)
+    kt = [s.kernel_times() for s in sols]
+    ia, ib = sols[0].info_arrays(), sols[1].info_arrays()
+    for k in ("n_iters", "n_ls_iters", "n_reg_iters", "status"):
+        assert np.array_equal(ia[k], ib[k]), k
+    assert (ia["n_ls_iters"] > 2 * ia["n_iters"]).any()          # probe launches happened
+    assert np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=1e-9)
+    for i in range(len(phases)):
+        for f in ("XBAR", "UBAR", "K", "Y"):
+            a, b = sols[0].field(i, f), sols[1].field(i, f)
+            assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(a).max()), (i, f, np.abs(a - b).max())

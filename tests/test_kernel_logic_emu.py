@@ -19,8 +19,16 @@ def emu_lib():
     return pkg._abi.bind(ctypes.CDLL(os.path.join(d, "libhsddp_emu.so")))
 
 
+@pytest.mark.parametrize("program", ["wave", "quad"])
 @pytest.mark.parametrize("which", ["stance", "trot", "mhpc", "srb_only", "barrel_roll", "hkd", "mpc_tick"])
-def test_kernel_programs_match_oracle(emu_lib, oracle_lib, oracle_ld_lib, which):
+def test_kernel_programs_match_oracle(emu_lib, oracle_lib, oracle_ld_lib, which, program, monkeypatch):
+    """program: which rollout program evaluates the whole-body running knots - the one-wave knot (wb_knot.hpp) or the lane-quad knot
+    (wb_quad.hpp: one lane per leg; here its four lanes run as a four-wide value).  Both write the trajectories AND the contact-solve cache the
+    LQ knot of the next step fetches, so the per-iterate comparison covers the cache layout too."""
+    if program == "quad":
+        if which in ("srb_only", "hkd"):
+            pytest.skip("no whole-body knot in this problem")
+        monkeypatch.setenv("HSDDP_EMU_QUAD", "1")
     if which == "mhpc":    # whole-body phases + single-rigid-body tail: mixed state dimension across the phase boundary
         phases = pkg.problems.mhpc_problem(wb_horizons=(4, 3), srb_horizons=(3, 2))
     else:
@@ -87,3 +95,37 @@ def test_single_shooting_programs_match_oracle(emu_lib, oracle_lib, which):
     for s_ in (so, se):
         s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
     pc.compare(so, se, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "ss1")
+
+
+def test_quad_probe_matches_the_one_wave_knot_slot_by_slot(emu_lib):
+    """The lane-quad program as a line-search PROBE (nothing written) against the one-wave knot: per (problem, knot) the three merit partials
+    cost, squared defect, min g at several step lengths, on schedules with 2 / 3 / 4 / 0 contact feet and the barrel roll's joint-speed barrier."""
+    raw = ctypes.CDLL(os.path.join(ROOT, "tests", "_emu", "libhsddp_emu.so"))
+
+    def partials(s, fn, *a):
+        nsl = sum(p["desc"].horizon + 1 for p in s.phases)
+        out = np.zeros((s.batch, nsl, 3))
+        assert getattr(raw, fn)(s.h, *a, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+    x2 = pkg.problems.wb_ensemble_x0(2, 20241222)
+    cases = [(pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3)), x2, pkg.mhpc_ddp_setting()),
+             (pkg.problems.wb_trot_problem(schedule=((1, 1, 1, 1), (0, 0, 0, 0), (1, 1, 0, 1)), horizons=(3, 3, 3), last_next=(1, 1, 1, 1)), x2, pkg.mhpc_ddp_setting())]
+    phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.03, 0.06, 0.10, 0.13, 0.16, 0.19))
+    cases.append((phases, np.vstack([xinit, xinit + 0.01 * (x2[0] - pkg.problems.wb_nominal_state())]), pkg.problems.br_ddp_setting()))
+    for phases, x0, opt in cases:
+        s = pkg.Solver(emu_lib, phases, batch=2)
+        for i, p in enumerate(phases):
+            s.set_nominal(i, p["Xbar"], p["Ubar"])
+        s.set_initial_condition(x0)
+        for it, eps in enumerate((0.0, 1.0, 0.25)):
+            s.hybrid_rollout(eps, opt)
+            a = partials(s, "hsddp_debug_slot_partials")
+            b = partials(s, "hsddp_debug_quad_probe", ctypes.c_double(eps), ctypes.byref(opt))
+            m = ~np.isnan(b[..., 0])
+            assert m.sum() == 2 * sum(p["desc"].horizon for p in phases)
+            for q in range(3):
+                assert np.abs(a[..., q][m] - b[..., q][m]).max() <= 1e-11 * max(1.0, np.abs(a[..., q][m]).max()), (it, q)
+            if it == 0:
+                s.update_nominal_trajectory()
+            s.LQ_approximation(opt); assert s.backward_sweep(0.0).all(); s.linear_rollout(1.0, opt)
+        s.close()
