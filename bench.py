@@ -50,8 +50,9 @@ def cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, steps, nprob=64):
     problem as the GPU run, on a bounded sample of the ensemble — reported baseline, not the target."""
     path = os.path.join(ROOT, "oracle", "liboracle_hsddp.so")
     if not os.path.exists(path):
-        return None
+        return None, None
     lib = pkg._abi.bind(ctypes.CDLL(path))
+    keep = None
     lib.oracle_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     # the GPU box exposes every host CPU in the affinity mask but a one-GPU job owns a 16-core share: size the pool to that
     cores = min(len(os.sched_getaffinity(0)), 16)
@@ -67,12 +68,45 @@ def cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, steps, nprob=64):
         t0 = time.time(); s.solve(opt); dt = time.time() - t0
         info = s.info_arrays()
         out[kind] = (float(info["n_iters"].sum()) / dt, float(info["n_ls_iters"].sum()) / max(float(info["n_iters"].sum()), 1.0), dt)
-        s.close()
-    return {"value": out["all_cores"][0], "unit": "DDP iterations/s", "cores": cores, "kind": "port",
+        if kind == "all_cores":
+            keep = s            # (kept open: parity_sample compares its results with the GPU's first problems)
+        else:
+            s.close()
+    return keep, {"value": out["all_cores"][0], "unit": "DDP iterations/s", "cores": cores, "kind": "port",
             "mean_ls_trials_per_iter": out["all_cores"][1], "seconds": round(out["all_cores"][2], 2),
             "sample": f"the first {nprob} problems of the same ensemble x {steps} iterations each (same options as the GPU run), one problem "
                       f"per core on {cores} threads; reference-shaped run (1 problem at a time, 4 OpenMP threads over knots in "
                       f"LQ_approximation only, 2 problems): {out['reference_shaped_4thr'][0]:.3f} it/s"}
+
+
+def parity_sample(sg, so, nph):
+    """The problems cpu_baseline solved on the oracle against the SAME problems of the timed GPU run (the oracle as checker of the bench's own
+    output): decisions must be identical, values agree to the parity tests' per-solve tolerances (tests/test_gpu_parity.py)."""
+    n = so.batch
+    ig, io = sg.info_arrays(), so.info_arrays()
+    out = {"problems": n, "n_iters_equal": bool(np.array_equal(ig["n_iters"][:n], io["n_iters"])), "n_ls_iters_equal": bool(np.array_equal(ig["n_ls_iters"][:n], io["n_ls_iters"])),
+           "n_reg_iters_equal": bool(np.array_equal(ig["n_reg_iters"][:n], io["n_reg_iters"])), "status_equal": bool(np.array_equal(ig["status"][:n], io["status"])),
+           "max_rel_dcost": float(np.max(np.abs(ig["actual_cost"][:n] - io["actual_cost"]) / np.maximum(np.abs(io["actual_cost"]), 1e-300))),
+           "max_abs_dfeas": float(np.max(np.abs(ig["dyn_feas"][:n] - io["dyn_feas"])))}
+    dK0 = dKall = dX = 0.0; kmax = 0.0
+    for i in range(nph):
+        kg, ko = sg.field(i, "K", 0, n), so.field(i, "K")
+        if i == 0:
+            dK0 = float(np.abs(kg[:, 0] - ko[:, 0]).max())
+        dKall = max(dKall, float(np.abs(kg - ko).max())); kmax = max(kmax, float(np.abs(ko).max()))
+        dX = max(dX, float(np.abs(sg.field(i, "XBAR", 0, n) - so.field(i, "XBAR")).max()))
+    out.update({"max_dK_inf_knot0": dK0, "max_dK_inf_all_knots": dKall, "max_abs_K": kmax, "max_dXbar_inf": dX,
+                "pass": bool(out["n_iters_equal"] and out["n_ls_iters_equal"] and out["status_equal"] and dKall < 1e-6 and out["max_rel_dcost"] < 1e-6)})
+    return out
+
+
+def load_profile_json(pkg, name):
+    """profiles/<name>: cited only while it was measured on the kernel sources this run executes (kernel_source_hash recorded by tools/pmc_summary.py)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return d if d.get("kernel_source_hash") == pkg.kernel_source_hash() else None
 
 
 def latency_probe(pkg, steps):
@@ -214,6 +248,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     s.solve(opt)                       # synchronises its stream before returning
+    my_solve_ms = (time.perf_counter() - t0) * 1e3
     rows = launch.result_rows(s.info_arrays())
     res_all = launch.gather_results(dist, rows, dev)      # C1: all-gather of the per-problem result struct (64 B/problem) over RCCL/xGMI
     torch.cuda.synchronize()
@@ -222,29 +257,37 @@ def main():
     dt = time.perf_counter() - t0
     dt = launch.max_over_ranks(dist, dt, dev)
     ranks_seen = int(round(launch.sum_over_ranks(dist, 1.0, dev)))
+    per_rank = launch.gather_scalars(dist, [my_solve_ms, float(rows[:, 4].sum()), float(rows[:, 5].sum())], dev)      # solve ms, iterations, line-search trials of every rank
     assert res_all.shape[0] == total, (res_all.shape, total)
     iters_done = float(res_all[:, 4].sum())
     if rank == 0:
         kt = s.kernel_times()
         knots = sum(p["desc"].horizon for p in s.phases)
         dom = max((k for k in kt if k in alg_bytes), key=lambda k: kt[k][0], default=None)
+        units_all = s.kernel_units()
+        traffic_all = None if args.hkd else load_profile_json(pkg, "traffic.json")       # PMC bytes per knot of the whole-body workload (tools/profile_round.sh)
+        counters = None if args.hkd else load_profile_json(pkg, "counters.json")          # SQ counters per knot (tools/pmc_lanes.sh)
+        per_kernel = {}
+        for kname in alg_bytes:
+            if kname not in kt or kt[kname][1] == 0:
+                continue
+            ms, n = kt[kname]
+            units = units_all.get(kname)
+            per_launch_bytes = alg_bytes[kname] * (units / n if units else knots * B)
+            ach = per_launch_bytes / (ms / n * 1e-3) / 1e9
+            per_kernel[kname] = {"avg_launch_ms": ms / n, "launches": n, "units_per_launch": (units / n if units else knots * B), "alg_bytes_per_unit": alg_bytes[kname],
+                                 "alg_bytes_per_launch": per_launch_bytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": (traffic_all or {}).get("kernels", {}).get(kname)}
         roof = None
         if dom:
-            ms, n = kt[dom]
-            units = s.kernel_units().get(dom)             # knots (x candidate steps) the launches of this kernel family processed
-            per_launch_bytes = alg_bytes[dom] * (units / n if units else knots * B)
-            achieved = per_launch_bytes / (ms / n * 1e-3) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            if os.path.exists(tf) and not args.hkd:      # (the counters were collected on the whole-body workload: no figure for --hkd)
-                traffic = json.load(open(tf)).get(dom)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "avg_launch_ms": ms / n, "launches": n, "alg_bytes_per_launch": per_launch_bytes,
-                    # what actually bounds the per-knot kernels (offline SQ counters, not measured by this run): fp64 VALU issue at two waves per SIMD
-                    "binding_resource": None if args.hkd else {"resource": "fp64 VALU issue", "simd_valu_utilisation": 0.65, "valu_instructions_per_rollout_knot": 3251,
-                                                               "source": "profiles/r02p_sq_counters.txt"},
+            d = per_kernel[dom]
+            roof = {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"], "traffic": d["traffic"],
+                    "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"], "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+                    "note": "algorithmic bytes / measured launch time against the HBM roof (the yardstick of SURVEY 8d); `kernels` carries the same figure for every hot "
+                            "kernel, `counters` what the SQ counters say binds them (only while measured on these kernel sources)",
+                    "kernels": per_kernel, "counters": (counters or {}).get("kernels"),
                     "kernel_ms": {k: round(v[0], 3) for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
-                    "kernel_units_knots": s.kernel_units(),
+                    "kernel_units_knots": units_all,
                     "whole_iteration": {"alg_bytes_per_knot_iteration": alg_total, "achieved_GBs": alg_total * knots * iters_done / dt / 1e9 / world,
                                         "frac_of_peak": alg_total * knots * iters_done / dt / 1e9 / world / HBM_PEAK_GBS}}
         line = {"metric": METRIC, "value": iters_done / dt, "unit": "DDP iterations/s",
@@ -254,8 +297,14 @@ def main():
                            "parallelism": f"ensemble-sharded x{world}", "n_status_ok": int((res_all[:, 7] == 0).sum()),
                            "mean_ls_trials_per_iter": float(res_all[:, 5].sum() / max(iters_done, 1))},
                 "roofline": roof}
+        line["per_rank"] = {"solve_ms": [round(float(v), 3) for v in per_rank[:, 0]], "iterations": [int(v) for v in per_rank[:, 1]], "ls_trials": [int(v) for v in per_rank[:, 2]],
+                            "iter_imbalance": float(per_rank[:, 1].max() / max(per_rank[:, 1].mean(), 1.0)), "time_imbalance": float(per_rank[:, 0].max() / max(per_rank[:, 0].mean(), 1e-9))}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, args.steps)
+            so, line["cpu_baseline"] = cpu_baseline(pkg, phases_fn, x0_fn, opt_fn, args.steps)
+            if so is not None:
+                if args.hkd != "f32":          # (an fp32 handle is outside the fp64 tolerances: tests/test_gpu_parity.py holds it to its own)
+                    line["parity_sample"] = parity_sample(s, so, len(s.phases))
+                so.close()
         if world == 1 and not args.no_latency and not args.strong and not args.hkd:
             line["latency"] = latency_probe(pkg, args.steps)
             line["latency"]["mpc_tick"] = mpc_tick_probe(pkg)

@@ -18,6 +18,17 @@ HIP_LIB_PATH = _os.path.join(_HERE, "libhsddp_hip.so")
 _lib = None
 
 
+def kernel_source_hash():
+    """sha256[:16] over the kernel sources (csrc/*.hpp, *.hip): profile summaries under profiles/ record the sources they were measured on,
+    bench.py only cites them while the hash still matches."""
+    import hashlib
+    d = _os.path.join(_HERE, "csrc"); hsh = hashlib.sha256()
+    for f in sorted(_os.listdir(d)):
+        if f.endswith((".hpp", ".hip")):
+            hsh.update(f.encode()); hsh.update(open(_os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def load_hip_library():
     """Load and bind libhsddp_hip.so. Raises (never falls back) if it is missing or incomplete."""
     global _lib

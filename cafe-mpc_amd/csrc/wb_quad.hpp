@@ -558,6 +558,37 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         qddl = bwd3(Ll, zl - V3<S>{et[0], et[1], et[2]});
     }
 
+    // ---- tail.  EVERY global read of the tail first, back to back and ahead of its stores (a store between two loads pins the later load behind
+    // it - the compiler cannot rule out aliasing - and a single wave per SIMD then pays one exposed round trip per load): the next knot's
+    // state, the knot's references, the barrier parameters of the lane's constraints.
+    const double dt = P.dt;
+    const HS_GLOBAL double* rr = P.rref + (size_t)k * 80;
+    const size_t gk = kk * P.ng;
+    S xnb[6], vnb[6], xnl[3], vnl[3], xrb[6], vrb[6], xrl[3], vrl[3], url[3], rel[3], fvr[3], rc;
+    S eT[6], dT[6], eS[6], dS[6], eJ[6], dJ[6], eH = zero, dH_ = S(1.0), eG[5], dG[5];
+    {
+        _Pragma("unroll") for (int i = 0; i < 6; i++) {
+            xnb[i] = Q::ld(P.Xbar, kx + 36 + i, 0) + eps * Q::ld(P.dX, kx + 36 + i, 0); vnb[i] = Q::ld(P.Xbar, kx + 54 + i, 0) + eps * Q::ld(P.dX, kx + 54 + i, 0);
+            xrb[i] = Q::ld(rr, i, 0); vrb[i] = Q::ld(rr, 18 + i, 0);
+        }
+        _Pragma("unroll") for (int j = 0; j < 3; j++) {
+            xnl[j] = Q::ld(P.Xbar, kx + 42 + j, 3) + eps * Q::ld(P.dX, kx + 42 + j, 3); vnl[j] = Q::ld(P.Xbar, kx + 60 + j, 3) + eps * Q::ld(P.dX, kx + 60 + j, 3);
+            xrl[j] = Q::ld(rr, 6 + j, 3); vrl[j] = Q::ld(rr, 24 + j, 3); url[j] = Q::ld(rr, 36 + j, 3); rel[j] = Q::ld(rr, 64 + j, 3); fvr[j] = Q::ld(rr, 48 + j, 3);
+        }
+        rc = Q::ld(rr, 60, 1);
+        // entries 0..2: lower-bound half of the lane's three joints, 3..5: upper-bound half (12 constraints further).  One uniform branch per
+        // constraint object AROUND its twelve loads (a branch per load would put a wait between every pair)
+        _Pragma("unroll") for (int j = 0; j < 6; j++) { eT[j] = zero; dT[j] = S(1.0); eS[j] = zero; dS[j] = S(1.0); eJ[j] = zero; dJ[j] = S(1.0); }
+        if (P.go_torque >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eT[j] = Q::ld(P.eps, gk + P.go_torque + o, 3); dT[j] = Q::ld(P.delta, gk + P.go_torque + o, 3); } }
+        if (P.go_jspeed >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eS[j] = Q::ld(P.eps, gk + P.go_jspeed + o, 3); dS[j] = Q::ld(P.delta, gk + P.go_jspeed + o, 3); } }
+        if (P.go_joint >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eJ[j] = Q::ld(P.eps, gk + P.go_joint + o, 3); dJ[j] = Q::ld(P.delta, gk + P.go_joint + o, 3); } }
+        if (P.go_height >= 0) { eH = Q::ld(P.eps, gk + P.go_height, 0); dH_ = Q::ld(P.delta, gk + P.go_height, 0); }
+        _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = zero; dG[r] = S(1.0); }
+        if (P.go_grf >= 0) {      // per-lane constraint index go_grf + 5 slot + r: a swing lane reads a valid dummy (slot 0) and contributes nothing
+            const S ci0 = Q::sel(on, 5.0 * before, S(0.0));      // (one per-lane base, constant offsets r: the five loads share an address register)
+            _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = Q::ldv(P.eps, gk + P.go_grf + r, ci0); dG[r] = Q::ldv(P.delta, gk + P.go_grf + r, ci0); }
+        }
+    }
     if (WR) {
         _Pragma("unroll") for (int c = 0; c < 6; c++) Q::st0(kc, KC_QDD + c, qddb[c]);
         Q::st(kc, KC_QDD + 6, 3, qddl.x); Q::st(kc, KC_QDD + 7, 3, qddl.y); Q::st(kc, KC_QDD + 8, 3, qddl.z);
@@ -565,15 +596,13 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         Q::stv(kc, KC_LAM, 3.0 * cb, all, lam.x); Q::stv(kc, KC_LAM + 1, 3.0 * cb, all, lam.y); Q::stv(kc, KC_LAM + 2, 3.0 * cb, all, lam.z);
     }
     // ---- integrate (forward Euler, WBM.cpp:25-26), defect of knot k+1, divergence norm
-    const double dt = P.dt;
     S dsq = zero, nsq = zero;
+    const S w0 = Q::legc(1.0, 0.0, 0.0, 0.0);      // the replicated base entries are counted once
     {
-        const S w0 = Q::legc(1.0, 0.0, 0.0, 0.0);      // the replicated base entries are counted once
         _Pragma("unroll")
         for (int i = 0; i < 6; i++) {
             const S xs = qb[i] + vb[i] * dt, vs = vb[i] + qddb[i] * dt;
-            const S xn = Q::ld(P.Xbar, kx + 36 + i, 0) + eps * Q::ld(P.dX, kx + 36 + i, 0), vn = Q::ld(P.Xbar, kx + 54 + i, 0) + eps * Q::ld(P.dX, kx + 54 + i, 0);
-            const S d0 = xs - xn, d1 = vs - vn;
+            const S d0 = xs - xnb[i], d1 = vs - vnb[i];
             dsq = dsq + w0 * (d0 * d0 + d1 * d1); nsq = nsq + w0 * (xs * xs + vs * vs);
             if (WR) { Q::st0(P.Xsim, kx + 36 + i, xs); Q::st0(P.Xsim, kx + 54 + i, vs); Q::st0(P.Defect, kx + 36 + i, d0); Q::st0(P.Defect, kx + 54 + i, d1); }
         }
@@ -581,8 +610,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         _Pragma("unroll")
         for (int j = 0; j < 3; j++) {
             const S xs = ql[j] + vl_[j] * dt, vs = vl_[j] + qd3[j] * dt;
-            const S xn = Q::ld(P.Xbar, kx + 42 + j, 3) + eps * Q::ld(P.dX, kx + 42 + j, 3), vn = Q::ld(P.Xbar, kx + 60 + j, 3) + eps * Q::ld(P.dX, kx + 60 + j, 3);
-            const S d0 = xs - xn, d1 = vs - vn;
+            const S d0 = xs - xnl[j], d1 = vs - vnl[j];
             dsq = dsq + (d0 * d0 + d1 * d1); nsq = nsq + (xs * xs + vs * vs);
             if (WR) { Q::st(P.Xsim, kx + 42 + j, 3, xs); Q::st(P.Xsim, kx + 60 + j, 3, vs); Q::st(P.Defect, kx + 42 + j, 3, d0); Q::st(P.Defect, kx + 60 + j, 3, d1); }
         }
@@ -607,20 +635,18 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     if (WR) { Q::st(P.Y, kk * 12, 3, lam.x); Q::st(P.Y, kk * 12 + 1, 3, lam.y); Q::st(P.Y, kk * 12 + 2, 3, lam.z); }
 
     // ---- running cost (QuadraticTrackingCost + the foot costs of MHPCCost.cpp:4-245), references of knot k from the phase's record
-    const HS_GLOBAL double* rr = P.rref + (size_t)k * 80;
     S lq;      // 0.5 (sum_x + sum_u) dt, formed like the wave kernel: l = 0.5 sx; l += 0.5 su; l *= dt
     S lfoot2, lfoot3, lfoot4;
     {
-        const S w0 = Q::legc(1.0, 0.0, 0.0, 0.0);
         S sxq = zero, suq = zero;
         _Pragma("unroll")
         for (int i = 0; i < 6; i++) {
-            const S dq = qb[i] - Q::ld(rr, i, 0), dv = vb[i] - Q::ld(rr, 18 + i, 0);
+            const S dq = qb[i] - xrb[i], dv = vb[i] - vrb[i];
             sxq = sxq + w0 * (dq * P.q[i] * dq + dv * P.q[18 + i] * dv);
         }
         _Pragma("unroll")
         for (int j = 0; j < 3; j++) {
-            const S dq = ql[j] - Q::ld(rr, 6 + j, 3), dv = vl_[j] - Q::ld(rr, 24 + j, 3), du = ul[j] - Q::ld(rr, 36 + j, 3);
+            const S dq = ql[j] - xrl[j], dv = vl_[j] - vrl[j], du = ul[j] - url[j];
             // the phase's weights of the lane's leg: scalars of the descriptor picked by the lane (a per-lane index would be a vector load from constant memory)
             const S wq = Q::legc(P.q[6 + j], P.q[9 + j], P.q[12 + j], P.q[15 + j]), wv = Q::legc(P.q[24 + j], P.q[27 + j], P.q[30 + j], P.q[33 + j]), wu = Q::legc(P.r[j], P.r[3 + j], P.r[6 + j], P.r[9 + j]);
             sxq = sxq + (dq * wq * dq + dv * wv * dv);
@@ -629,9 +655,8 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         sxq = Q::sum(sxq); suq = Q::sum(suq);
         lq = 0.5 * sxq; lq = lq + 0.5 * suq; lq = lq * dt;
         // foot costs of the lane's foot
-        const S rc = Q::ld(rr, 60, 1);
-        const V3<S> d = {(fpos.x - qb[0]) - Q::ld(rr, 64, 3), (fpos.y - qb[1]) - Q::ld(rr, 65, 3), (fpos.z - qb[2]) - Q::ld(rr, 66, 3)};
-        const V3<S> dv = {fvel.x - Q::ld(rr, 48, 3), fvel.y - Q::ld(rr, 49, 3), fvel.z - Q::ld(rr, 50, 3)};
+        const V3<S> d = {(fpos.x - qb[0]) - rel[0], (fpos.y - qb[1]) - rel[1], (fpos.z - qb[2]) - rel[2]};
+        const V3<S> dv = {fvel.x - fvr[0], fvel.y - fvr[1], fvel.z - fvr[2]};
         const typename Q::B stance = Q::gt(rc, S(0.0)), swing = Q::gt(S(0.5), rc);      // (rc == 0 <=> swing: the flags are 0 / 1)
         const S wr0 = P.w_foot_reg[0], wr1 = P.w_foot_reg[1], wr2 = P.w_foot_reg[2], wp0 = P.w_swing_pos[0], wp1 = P.w_swing_pos[1], wp2 = P.w_swing_pos[2];
         const S wv0 = P.w_swing_vel[0], wv1 = P.w_swing_vel[1], wv2 = P.w_swing_vel[2];
@@ -647,33 +672,20 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     // ---- path constraints of the lane's leg (MHPCConstraint.cpp:9-204): values, ReB cost per constraint object, minimum
     S gmin = zero;
     {
-        const size_t gk = kk * P.ng;
-        auto one = [&](const S& g, int c0, int cstride, S& acc) {      // constraint index c0 + cstride * lane
-            const S e = Q::ld(P.eps, gk + c0, cstride), dl = Q::ld(P.delta, gk + c0, cstride);
-            if (WR) Q::st(P.g, gk + c0, cstride, g);
-            acc = acc + e * q_barrier<Q, S>(g, dl); gmin = Q::min(gmin, g);
+        auto six = [&](const S (&g)[6], const S (&e)[6], const S (&dl)[6], int c0) {      // one constraint object: entries j / 12 + j of the lane's three joints
+            S acc = zero;
+            _Pragma("unroll") for (int j = 0; j < 6; j++) { acc = acc + e[j] * q_barrier<Q, S>(g[j], dl[j]); gmin = Q::min(gmin, g[j]); }
+            if (WR) { _Pragma("unroll") for (int j = 0; j < 6; j++) Q::st(P.g, gk + c0 + ((j < 3) ? j : 12 + j - 3), 3, g[j]); }
+            if (reb_active) l = l + dt * Q::sum(acc);
         };
-        if (P.go_torque >= 0) {
-            S acc = zero;
-            _Pragma("unroll") for (int j = 0; j < 3; j++) { one(-ul[j] + P.torque_limit, P.go_torque + j, 3, acc); one(ul[j] + P.torque_limit, P.go_torque + 12 + j, 3, acc); }
-            if (reb_active) l = l + dt * Q::sum(acc);
-        }
-        if (P.go_jspeed >= 0) {
-            S acc = zero;
-            _Pragma("unroll") for (int j = 0; j < 3; j++) { one(vl_[j] - P.jspeed_lb, P.go_jspeed + j, 3, acc); one(-vl_[j] + P.jspeed_ub, P.go_jspeed + 12 + j, 3, acc); }
-            if (reb_active) l = l + dt * Q::sum(acc);
-        }
-        if (P.go_joint >= 0) {
-            S acc = zero;
-            _Pragma("unroll") for (int j = 0; j < 3; j++) { one(ql[j] - P.joint_lb[j], P.go_joint + j, 3, acc); one(-ql[j] + P.joint_ub[j], P.go_joint + 12 + j, 3, acc); }
-            if (reb_active) l = l + dt * Q::sum(acc);
-        }
+        if (P.go_torque >= 0) { const S g[6] = {-ul[0] + P.torque_limit, -ul[1] + P.torque_limit, -ul[2] + P.torque_limit, ul[0] + P.torque_limit, ul[1] + P.torque_limit, ul[2] + P.torque_limit}; six(g, eT, dT, P.go_torque); }
+        if (P.go_jspeed >= 0) { const S g[6] = {vl_[0] - P.jspeed_lb, vl_[1] - P.jspeed_lb, vl_[2] - P.jspeed_lb, -vl_[0] + P.jspeed_ub, -vl_[1] + P.jspeed_ub, -vl_[2] + P.jspeed_ub}; six(g, eS, dS, P.go_jspeed); }
+        if (P.go_joint >= 0) { const S g[6] = {ql[0] - P.joint_lb[0], ql[1] - P.joint_lb[1], ql[2] - P.joint_lb[2], -ql[0] + P.joint_ub[0], -ql[1] + P.joint_ub[1], -ql[2] + P.joint_ub[2]}; six(g, eJ, dJ, P.go_joint); }
         if (P.go_height >= 0) {      // one constraint: evaluated by every lane on the same data, counted once
             const S g = qb[2] - P.h_min;
-            const S e = Q::ld(P.eps, gk + P.go_height, 0), dl = Q::ld(P.delta, gk + P.go_height, 0);
             if (WR) Q::st0(P.g, gk + P.go_height, g);
             gmin = Q::min(gmin, g);
-            if (reb_active) l = l + dt * (e * q_barrier<Q, S>(g, dl));
+            if (reb_active) l = l + dt * (eH * q_barrier<Q, S>(g, dH_));
         }
         if (P.go_grf >= 0) {      // friction pyramid of the lane's foot; its slot among the contact feet = number of contact feet before it
             S acc = zero;
@@ -681,12 +693,9 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
             const S gs[5] = {lam.z, -lam.x + mu * lam.z, lam.x + mu * lam.z, -lam.y + mu * lam.z, lam.y + mu * lam.z};
             _Pragma("unroll")
             for (int r = 0; r < 5; r++) {
-                // per-lane constraint index go_grf + 5 slot + r: a swing lane reads a valid dummy (slot 0) and contributes nothing
-                const S ci = Q::sel(on, 5.0 * before + (double)r, S(0.0));
-                const S e = Q::ldv(P.eps, gk + P.go_grf, ci), dl = Q::ldv(P.delta, gk + P.go_grf, ci);
                 const S g = Q::sel(on, gs[r], S(1.0));
-                if (WR) Q::stv(P.g, gk + P.go_grf, ci, on, g);
-                acc = acc + Q::sel(on, e * q_barrier<Q, S>(g, dl), zero);
+                if (WR) Q::stv(P.g, gk + P.go_grf, Q::sel(on, 5.0 * before + (double)r, S(0.0)), on, g);
+                acc = acc + Q::sel(on, eG[r] * q_barrier<Q, S>(g, dG[r]), zero);
                 gmin = Q::min(gmin, Q::sel(on, g, zero));
             }
             if (reb_active) l = l + dt * Q::sum(acc);

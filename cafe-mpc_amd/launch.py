@@ -21,6 +21,28 @@ def free_port():
         return s.getsockname()[1]
 
 
+def count_gpus_without_hip():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of the ranks must not initialise the GPU): KFD topology
+    nodes with SIMDs under /sys/class/kfd, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None when the topology is not readable
+    (no amdgpu driver on this host): the ranks then find out themselves and fail loudly."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return None
+    n = 0
+    for node in sorted(os.listdir(root)):
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(root, node, "properties")).read().splitlines() if " " in line)
+        except OSError:        # (a node of another container's cgroup: not ours)
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def maybe_spawn(n_ranks, script, argv, require_gpus=True):
     """Parent side of `bench.py --gpus N` started WITHOUT a launcher: start N ranks (torch.distributed.run, one per GPU) as child
     processes and relay their output.  Must run before this process makes any GPU call (a process that has initialised the GPU must
@@ -33,15 +55,19 @@ def maybe_spawn(n_ranks, script, argv, require_gpus=True):
     if n_ranks <= 1:
         return None
     if require_gpus:
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU
-        if have < n_ranks:
+        have = count_gpus_without_hip()
+        if have is None:
+            have = 0 if not os.path.exists("/dev/kfd") else None      # no amdgpu device node at all: certainly no GPU here
+        if have is not None and have < n_ranks:
             print(f"[launch] --gpus {n_ranks} requested but this node exposes {have} GPU(s): refusing to run fewer ranks than asked", file=sys.stderr)
             return 3
     port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), script] + list(argv)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # HSA_ENABLE_IPC_MODE_LEGACY: the pool's host driver only supports dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument);
+    # the image exports 0 already - an explicit setting of the caller is passed through untouched
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
 
@@ -109,3 +135,15 @@ def sum_over_ranks(dist, value, device):
     t = torch.tensor([value], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_scalars(dist, values, device):
+    """[world, len(values)] fp64: a few per-rank scalars (solve time, iteration count) on every rank - explains a scaling result by rank."""
+    row = np.asarray(values, dtype=np.float64)[None]
+    if dist is None:
+        return row
+    import torch
+    t = torch.as_tensor(row, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return np.concatenate([o.cpu().numpy() for o in out])

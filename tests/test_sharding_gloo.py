@@ -27,17 +27,27 @@ WORKER = textwrap.dedent("""
     assert world == 2 and dist.get_world_size() == 2
     lib = pkg._abi.bind(ctypes.CDLL(os.path.join(sys.argv[1], "oracle", "liboracle_hsddp.so")))
     first, B = launch.shard(TOTAL, world, rank)
-    phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+    if len(sys.argv) > 4 and sys.argv[4] == "strong":      # bench.py --strong in shape: the barrel-roll ensemble, a FIXED total split over the ranks
+        phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.03, 0.06, 0.10, 0.13, 0.16, 0.19))
+        x0 = pkg.problems.barrel_roll_ensemble_x0(B, 20241220 + 4, xinit, first=first)
+        opt = pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0)
+    else:
+        phases = pkg.problems.wb_trot_problem(horizons=(4, 3, 3, 3))
+        x0 = pkg.problems.wb_ensemble_x0(B, 99, first=first)                     # this rank's slice of the stream
+        opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0)
     s = pkg.Solver(lib, phases, batch=B)
     for i, p in enumerate(phases):
         s.set_nominal(i, p["Xbar"], p["Ubar"])
-    s.set_initial_condition(pkg.problems.wb_ensemble_x0(B, 99, first=first))     # this rank's slice of the stream
-    s.solve(pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0))
-    rows = launch.gather_results(dist, launch.result_rows(s.info_arrays()), "cpu")
+    s.set_initial_condition(x0)
+    s.solve(opt)
+    rows = launch.result_rows(s.info_arrays())
+    gathered = launch.gather_results(dist, rows, "cpu")
     slowest = launch.max_over_ranks(dist, float(rank), "cpu")
+    per_rank = launch.gather_scalars(dist, [float(rank) + 0.5, float(rows[:, 4].sum())], "cpu")      # what bench.py reports as per_rank
     if rank == 0:
         assert slowest == 1.0
-        np.save(sys.argv[2], rows)
+        assert per_rank.shape == (2, 2) and per_rank[0, 0] == 0.5 and per_rank[1, 0] == 1.5 and per_rank[:, 1].sum() == gathered[:, 4].sum()
+        np.save(sys.argv[2], gathered)
     dist.barrier(); dist.destroy_process_group()
 """)
 
@@ -59,6 +69,44 @@ def test_sharded_equals_unsharded(oracle_lib, tmp_path):
     ref = pkg.launch.result_rows(s.info_arrays())
     assert gathered.shape == ref.shape
     assert np.array_equal(gathered, ref)          # same oracle, same inputs -> bit-identical, ordering included
+
+
+def test_strong_scaling_split_of_the_barrel_roll_ensemble(oracle_lib, tmp_path):
+    """`bench.py --strong` in shape (config 4's ensemble, a fixed total split over the ranks, uneven blocks 3 + 2): every rank draws ITS slice of
+    the joint-pose stream (barrel_roll_ensemble_x0(first=...)), gathered == unsharded bit for bit, the per-rank scalars arrive in rank order."""
+    w = tmp_path / "worker.py"; w.write_text(WORKER)
+    out = tmp_path / "gathered.npy"
+    TOTAL = 5
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    subprocess.check_call([sys.executable, str(w), ROOT, str(out), str(TOTAL), "strong"], env=env, timeout=900)
+    gathered = np.load(out)
+    phases, xinit = pkg.problems.barrel_roll_problem(switching_times=(0.0, 0.03, 0.06, 0.10, 0.13, 0.16, 0.19))
+    s = pkg.Solver(oracle_lib, phases, batch=TOTAL)
+    for i, p in enumerate(phases):
+        s.set_nominal(i, p["Xbar"], p["Ubar"])
+    s.set_initial_condition(pkg.problems.barrel_roll_ensemble_x0(TOTAL, 20241220 + 4, xinit))
+    s.solve(pkg.problems.br_ddp_setting(max_AL_iter=1, max_DDP_iter=2, cost_thresh=0.0))
+    assert np.array_equal(gathered, pkg.launch.result_rows(s.info_arrays()))
+
+
+def test_gpu_count_without_the_hip_runtime(tmp_path, monkeypatch):
+    """The parent of the ranks counts GPUs from the KFD topology (no HIP call): here there is no amdgpu driver -> None; a fake topology is parsed
+    (nodes with SIMDs are GPUs, the CPU node is not) and cut down by HIP_VISIBLE_DEVICES."""
+    assert pkg.launch.count_gpus_without_hip() is None or isinstance(pkg.launch.count_gpus_without_hip(), int)
+    import builtins
+    root = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024, 1024)):
+        (root / str(i)).mkdir(parents=True); (root / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\n")
+    real_isdir, real_listdir, real_open = os.path.isdir, os.listdir, builtins.open
+    kfd = "/sys/class/kfd/kfd/topology/nodes"
+    monkeypatch.setattr(os.path, "isdir", lambda p: True if p == kfd else real_isdir(p))
+    monkeypatch.setattr(os, "listdir", lambda p: real_listdir(str(root)) if p == kfd else real_listdir(p))
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace(kfd, str(root)), *a, **k))
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False); monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert pkg.launch.count_gpus_without_hip() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert pkg.launch.count_gpus_without_hip() == 2
 
 
 def test_ensemble_stream_offsets():

@@ -3,6 +3,9 @@
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
+SRC_HASH = ge.load_package().kernel_source_hash()
 tag = sys.argv[1]
 out = f"gpurun_out/{tag}"
 
@@ -46,7 +49,14 @@ fetch, nf = counter_by_kernel("pmc_fetch", "FETCH_SIZE")
 write, nw = counter_by_kernel("pmc_write", "WRITE_SIZE")
 bl = last_json_line(f"{out}/pmc_fetch_bench.json") or {}
 units = (bl.get("roofline") or {}).get("kernel_units_knots", {})
-# k_rollout (the kernel function) serves both the ordinary rollouts and the probe launches of the batched line search: its unit count is the sum
+# The rollout family = k_rollout_quad (whole-body running knots on lane quads) + k_rollout (terminal knots, single-rigid-body tail), ordinary
+# rollouts and the probe launches of the batched line search alike: bytes of both kernels over the knots (x candidates) both families processed
+for acc in (fetch, write):
+    if "k_rollout_quad" in acc:
+        acc["k_rollout"] = acc.get("k_rollout", 0.0) + acc.pop("k_rollout_quad")
+for cnt in (nf, nw):
+    if "k_rollout_quad" in cnt:
+        cnt["k_rollout"] = cnt.get("k_rollout", 0) + cnt.pop("k_rollout_quad")
 units_by_kernel = {"k_rollout": units.get("k_rollout", 0) + units.get("k_ls_probe", 0), "k_lq": units.get("k_lq", 0), "k_sweep": units.get("k_sweep", 0), "k_sweep32": units.get("k_sweep", 0)}
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (kernel-trace only); command: bench.py --steps 12 --warmup 0 "
                 "--batch 512 --no-cpu-baseline --no-latency.  Counters are in KB, summed over every launch of a kernel in the run and divided by the knots "
@@ -69,6 +79,8 @@ if "k_rollout" in traffic:
     traffic["k_ls_probe"] = dict(traffic["k_rollout"], note="same kernel function as k_rollout (probe launches): run-wide average per knot x candidate")
 if not res["kernels"]:
     sys.exit(f"no PMC data under {out}: nothing written")
+res["kernel_source_hash"] = SRC_HASH
 json.dump(res, open(f"profiles/{tag}_pmc_batch512.json", "w"), indent=1)
-json.dump(traffic, open("profiles/r02_traffic.json", "w"), indent=1)
+# the file bench.py cites (roofline.traffic), valid only for the kernel sources it was measured on
+json.dump({"kernel_source_hash": SRC_HASH, "tag": tag, "kernels": traffic}, open("profiles/traffic.json", "w"), indent=1)
 print("wrote profiles/%s_*" % tag, list(res["kernels"]))
