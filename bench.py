@@ -174,6 +174,33 @@ def mpc_tick_probe(pkg, ticks=24):
     return out
 
 
+def mpc_tick_cpp_probe(ticks=24):
+    """The same loop on the reference-shaped C++ host path (tests/cpp/mpc_loop.cpp: C++ problem builder update + describe, reconfigure,
+    set_initial_condition, solve(opt, 0.9 dt_mpc), command + solver-info export), per-tick wall time INCLUDING the descriptor building - the
+    figure to hold against the reference's 18 ms (MHPCLocomotion.cpp:122).  Compiled here with g++ against libhsddp_hip.so."""
+    import shutil, subprocess, tempfile
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    if shutil.which("g++") is None or not os.path.isdir(tree):
+        return None
+    pkg = ge.load_package()
+    import importlib
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "mpc_loop")
+        try:
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                                   os.path.join(ROOT, "tests", "cpp", "mpc_loop.cpp"), "-L", os.path.join(ROOT, "cafe-mpc_amd"), "-lhsddp_hip",
+                                   "-Wl,-rpath," + os.path.join(ROOT, "cafe-mpc_amd"), "-o", exe], timeout=120)
+            open(os.path.join(td, "opt.bin"), "wb").write(bytes(builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")))
+            out = json.loads(subprocess.check_output([exe, tree, "bound", os.path.join(td, "opt.bin"), str(ticks)], timeout=120))
+        except Exception as e:      # (a measurement leg: never takes the bench line down)
+            return {"error": str(e)[:200]}
+    keep = {k: v for k, v in out.items() if k.endswith(("_mean", "_max")) or k in ("ticks", "budget_ms", "max_cputime_ms", "device_allocations_in_warm_ticks")}
+    keep["config"] = "tests/cpp/mpc_loop.cpp on libhsddp_hip.so: shipped bound gait, 25 WB + 10 SRB knots, runtime limits (4 AL x 1 DDP), batch 1, max_cputime = 0.9 dt_mpc"
+    keep["all_ticks_status_0"] = all(v == 0 for v in out["status"])
+    return keep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,6 +335,7 @@ def main():
         if world == 1 and not args.no_latency and not args.strong and not args.hkd:
             line["latency"] = latency_probe(pkg, args.steps)
             line["latency"]["mpc_tick"] = mpc_tick_probe(pkg)
+            line["latency"]["mpc_tick_cpp"] = mpc_tick_cpp_probe()
         print(json.dumps(line), flush=True)
     s.close()
     if dist is not None:

@@ -89,7 +89,7 @@ EXPORTS = ["hsddp_create", "hsddp_create_ex", "hsddp_precision", "hsddp_destroy"
            "hsddp_linear_rollout", "hsddp_update_nominal_trajectory", "hsddp_get_exp_cost_change",
            "hsddp_measure_dynamics_feasibility", "hsddp_get_info", "hsddp_get_field", "hsddp_field_shape",
            "hsddp_get_solve_time_ms", "hsddp_get_kernel_times", "hsddp_get_kernel_units", "hsddp_reset_kernel_times", "hsddp_get_history",
-           "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_reconfigure", "hsddp_debug_malloc_count", "hsddp_backend_name"]
+           "hsddp_export_mpc_command", "hsddp_warm_start_phase", "hsddp_reconfigure", "hsddp_set_control_knot", "hsddp_export_solver_info", "hsddp_debug_malloc_count", "hsddp_backend_name"]
 
 
 def bind(lib):
@@ -125,6 +125,8 @@ def bind(lib):
     lib.hsddp_export_mpc_command.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     lib.hsddp_warm_start_phase.argtypes = [H, C.c_int, H, C.c_int, C.c_int]
     lib.hsddp_reconfigure.argtypes = [H, C.c_int, C.POINTER(PhaseDesc), IP, IP]
+    lib.hsddp_set_control_knot.argtypes = [H, C.c_int, C.c_int, C.c_void_p]
+    lib.hsddp_export_solver_info.argtypes = [H, C.c_int, C.c_void_p]
     lib.hsddp_debug_malloc_count.argtypes = []
     lib.hsddp_debug_malloc_count.restype = C.c_longlong
     lib.hsddp_backend_name.argtypes = []
@@ -260,6 +262,20 @@ class Solver:
         self.phases = phases
         self.dims = [MODEL_DIMS[p["desc"].model] for p in phases]
         self.horizons = [p["desc"].horizon for p in phases]
+
+    def export_solver_info(self, problem=0):
+        """solver_info_lcmt content (MHPCLocomotion.cpp:74-79) of one problem: dict + the eight raw 32-bit words."""
+        w = np.zeros(8, dtype=np.uint32)
+        self._ck(self.lib.hsddp_export_solver_info(self.h, problem, w.ctypes.data_as(C.c_void_p)), "export_solver_info")
+        f = w[3:].view(np.float32)
+        return {"n_iter": int(w[0].view(np.int32)), "n_ls_iter": int(w[1].view(np.int32)), "n_reg_iter": int(w[2].view(np.int32)), "solve_time": float(f[0]), "cost": float(f[1]),
+                "dyn_feas": float(f[2]), "ineq_violation": float(f[3]), "eq_violation": float(f[4]), "raw": w}
+
+    def set_control_knot(self, phase, k, u=None):
+        """Trajectory::Ubar[k] (and U[k]) of one phase for the whole batch; u: [batch, m] or None for zeros (HKDProblem.cpp:220)."""
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64); assert u.shape == (self.batch, self.dims[phase][1])
+        self._ck(self.lib.hsddp_set_control_knot(self.h, phase, k, u.ctypes.data_as(C.c_void_p) if u is not None else None), "set_control_knot")
 
     CMD_FIELDS = (("mpc_times", 1, "f"), ("torque", 12, "f"), ("eul", 3, "f"), ("pos", 3, "f"), ("qJ", 12, "f"), ("vWorld", 3, "f"),
                   ("eulrate", 3, "f"), ("qJd", 12, "f"), ("GRF", 12, "f"), ("feedback", 432, "f"), ("Qu", 12, "f"), ("Quu", 144, "f"),

@@ -358,46 +358,124 @@ def load_hkd_constraint_params(path):
     return dict(grf=reb("GRF"), swing=reb("Swing"), td=Al(float(td["sigma"]), float(td["lambda"]), float(td["sigma_max"])))
 
 
-def build_hkd_problem(ref, cpar, plan_duration=0.6, dt_sim=0.01, nsteps_between_mpc=2):
-    """HKDProblem::initialization (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:14-97) with the constants of HKDMPCSolver::initialize
-    (HKDMPC/HKDMPC.cpp:26-29).  `ref` must have been loaded with reorder=True (HKDMPC.h:32: legs FR FL HR HL, qJd zeroed).
-    Returns (phases, info)."""
-    plan = F32(plan_duration); dt = F32(dt_sim); dt_mpc = F32(dt * F32(nsteps_between_mpc))
-    ref.initialize(plan)
-    starts, ends, hors, contacts = [], [], [], []
-    t = F32(0); start = F32(0)
-    c_prev = ref.contact_at(t)
-    while _approx_leq(t, plan):                                                # HKDProblem.cpp:34-63
-        c_cur = ref.contact_at(t)
-        if (c_cur != c_prev).any() or (float(t) > float(plan) or _approx_eq(t, plan)):
-            end = t
-            starts.append(start); ends.append(end); hors.append(int(round(float(F32(end - start) / dt)))); contacts.append(c_prev.copy())
-            c_prev = c_cur; start = end
-        t = F32(t + dt)
+class HKDProblemData:
+    """Phase table of HKDProblemData + the rules that evolve it: HKDProblem::initialization (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:14-111) with the
+    constants of HKDMPCSolver::initialize (HKDMPC/HKDMPC.cpp:26-29), and the receding-horizon HKDProblem::update (:117-222).  `ref` must have
+    been loaded with reorder=True (HKDMPC.h:32: legs FR FL HR HL, qJd zeroed).  `describe()` emits the descriptors of the current window,
+    `update()` advances one MPC step (nsteps_between_mpc simulation steps) and returns the slot map {uid: (front_popped, pushed, old_h)} of
+    the surviving phases - the same contract as MHPCProblemData, so shift_solver_in_place / hsddp_reconfigure serve both."""
 
+    def __init__(self, ref, cpar, plan_duration=0.6, dt_sim=0.01, nsteps_between_mpc=2):
+        self.ref, self.cpar = ref, cpar
+        self.plan = F32(plan_duration); self.dt = F32(dt_sim); self.nsteps = int(nsteps_between_mpc); self.dt_mpc = F32(self.dt * F32(nsteps_between_mpc))
+        ref.initialize(self.plan)
+        self.start, self.end, self.h, self.contact, self.reach_end, self.has_td, self.shooting, self.uid = [], [], [], [], [], [], [], []
+        self._next_uid = 0
+        self.ref_start = F32(0)                                                # QuadReference::get_start_time
+        self.dup_td = 0                                                        # phases that would carry TWO TouchDownConstraint objects in the reference (see update)
+        t = F32(0); start = F32(0)
+        c_prev = ref.contact_at(t)
+        while _approx_leq(t, self.plan):                                       # HKDProblem.cpp:34-63
+            c_cur = ref.contact_at(t)
+            if (c_cur != c_prev).any() or (float(t) > float(self.plan) or _approx_eq(t, self.plan)):
+                end = t
+                self._push_phase(start, end, int(round(float(F32(end - start) / self.dt))), c_prev.copy(), shooting=1)      # reach_end: (c != c).any() = false (:51)
+                c_prev = c_cur; start = end
+            t = F32(t + self.dt)
+        for i in range(len(self.h)):                                           # add_tconstr_one_phase for every phase at initialisation (:93)
+            self.has_td[i] = bool(self._touchdown(i).any())
+
+    def _push_phase(self, start, end, h, contact, shooting):
+        self.start.append(F32(start)); self.end.append(F32(end)); self.h.append(h); self.contact.append(contact); self.reach_end.append(False)
+        self.has_td.append(False); self.shooting.append(shooting); self.uid.append(self._next_uid); self._next_uid += 1
+
+    def _next_contact(self, i):                                                # add_tconstr_one_phase (:283-291)
+        if i + 1 < len(self.h):
+            return self.contact[i + 1]
+        return self.ref.contact_at(F32(self.plan + self.dt_mpc))
+
+    def _touchdown(self, i):
+        nxt = self._next_contact(i)
+        return np.array([1 if (self.contact[i][l] == 0 and nxt[l] == 1) else 0 for l in range(4)])
+
+    def update(self):
+        """HKDProblem::update (:117-222): per simulation step the reference steps, the front phase loses a knot (or disappears), the back either
+        grows by a knot or - once its end has been seen (is_phase_reach_end) - a new one-knot phase is appended; afterwards every phase but a
+        last one of at most two knots gets its shooting nodes (:211-216) and the first control of the window is zeroed (:218, the caller does
+        that through hsddp_set_control_knot).  Deviation (documented, counted in dup_td): add_tconstr_one_phase runs again on a phase that
+        already got its TouchDownConstraint at initialisation (the initial LAST phase, when a touchdown follows it within dt_mpc of the
+        horizon end), which leaves two identical constraint objects on it in the reference; here a phase has the constraint once."""
+        ref = self.ref
+        old = {u: h for u, h in zip(self.uid, self.h)}
+        popped = {u: 0 for u in self.uid}; pushed = {u: 0 for u in self.uid}
+        for _ in range(self.nsteps):
+            k_before = ref.k_cur
+            ref.step(self.dt)
+            self.ref_start = F32(float(self.ref_start) + (ref.k_cur - k_before) * float(ref.dt))
+            new_start = self.ref_start; new_end = F32(new_start + self.plan)
+            self.start[0] = F32(self.start[0] + self.dt)                       # front end (:131-146)
+            if _approx_leq(self.end[0], new_start):
+                for lst in (self.start, self.end, self.h, self.contact, self.reach_end, self.has_td, self.shooting, self.uid):
+                    lst.pop(0)
+            else:
+                popped[self.uid[0]] += 1; self.h[0] -= 1; self.start[0] = new_start
+            new_contact = ref.contact_at(F32(new_end - new_start))             # back end (:149-199)
+            change = bool((new_contact != self.contact[-1]).any())
+            if change and self.reach_end[-1]:
+                nstart = self.end[-1]
+                self._push_phase(nstart, new_end, int(round(float(F32(new_end - nstart) / self.dt))), new_contact.copy(), shooting=0)      # no update_SS_config yet
+                popped[self.uid[-1]] = 0; pushed[self.uid[-1]] = 0
+            else:
+                self.end[-1] = new_end; self.h[-1] += 1
+                if change:
+                    self.reach_end[-1] = True
+                pushed[self.uid[-1]] += 1
+            if self.reach_end[-1]:                                             # add_tconstr_one_phase on the last phase (:201-204)
+                td = bool(self._touchdown(len(self.h) - 1).any())
+                if td and self.has_td[-1]:
+                    self.dup_td += 1
+                self.has_td[-1] = self.has_td[-1] or td
+        n = len(self.h)
+        for i in range(n):                                                     # :207-216
+            if i < n - 1 or self.h[i] > 2:
+                self.shooting[i] = 1
+        return {u: (popped[u], pushed[u], old.get(u)) for u in self.uid}
+
+    @staticmethod
     def hkd_x(a):                                                              # HKDSinglePhaseReference::get_reference_at_t (HKDReference.cpp:23-61)
         b = a["body_state"]
         q = np.concatenate([a["foot_placements"][3 * l:3 * l + 3] if a["contact"][l] > 0 else a["jnt_angle"][3 * l:3 * l + 3] for l in range(4)])
         return np.concatenate([b[3:6], b[0:3], b[9:12], b[6:9], q])
 
-    phases = []
-    n = len(starts)
-    for i in range(n):
-        h = hors[i]
-        nxt = contacts[i + 1] if i + 1 < n else ref.contact_at(F32(plan + dt_mpc))         # HKDProblem.cpp:283-291
-        t_off = float(F32(starts[i] - starts[0]))
-        xr = np.zeros((h + 1, 24)); ur = np.zeros((h + 1, 24)); fp = np.zeros((h + 1, 12)); bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32)
-        X0 = np.zeros((h + 1, 24))
-        for k in range(h + 1):
-            a = ref.at(F32(t_off + k * float(dt)))
-            xr[k] = hkd_x(a); ur[k] = np.concatenate([a["grf"], a["jnt_vel"]]); fp[k] = a["foot_placements"]; bp[k] = a["body_state"][:3]; rc[k] = a["contact"]
-            X0[k] = hkd_x(ref.at(F32(float(starts[i]) + k * float(dt))))
-        ph = problems.hkd_phase(h, float(dt), t_off, contacts[i], nxt, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
-        ph["desc"].reb_grf = cpar["grf"]; ph["desc"].al_td = cpar["td"]
-        ph["Xbar"] = X0; ph["Ubar"] = np.zeros((h, 24))
-        phases.append(ph)
-    info = dict(start_times=[float(s) for s in starts], end_times=[float(e) for e in ends], horizons=hors, contacts=[c.tolist() for c in contacts], x0=phases[0]["Xbar"][0].copy())
-    return phases, info
+    def describe(self, ubar_mode=None):      # (ubar_mode: signature of MHPCProblemData.describe; the kinodynamic nominal controls start at zero, HKDProblem.cpp:75)
+        ref, dt, cpar = self.ref, self.dt, self.cpar
+        phases = []
+        n = len(self.h)
+        for i in range(n):
+            h = self.h[i]
+            nxt = self._next_contact(i)
+            t_off = float(F32(self.start[i] - self.start[0]))
+            xr = np.zeros((h + 1, 24)); ur = np.zeros((h + 1, 24)); fp = np.zeros((h + 1, 12)); bp = np.zeros((h + 1, 3)); rc = np.zeros((h + 1, 4), dtype=np.int32)
+            X0 = np.zeros((h + 1, 24))
+            for k in range(h + 1):
+                a = ref.at(F32(t_off + k * float(dt)))
+                xr[k] = self.hkd_x(a); ur[k] = np.concatenate([a["grf"], a["jnt_vel"]]); fp[k] = a["foot_placements"]; bp[k] = a["body_state"][:3]; rc[k] = a["contact"]
+                X0[k] = self.hkd_x(ref.at(F32(float(F32(self.start[i] - self.ref_start)) + k * float(dt))))      # initial guess (:80-85; only used by the first window)
+            ph = problems.hkd_phase(h, float(dt), t_off, self.contact[i], nxt, dict(xr=xr, ur=ur, foot_pos=fp, foot_vel=np.zeros((h + 1, 12)), body_pos=bp, ref_contact=rc))
+            d = ph["desc"]
+            d.reb_grf = cpar["grf"]; d.al_td = cpar["td"]; d.shooting = self.shooting[i]
+            if not self.has_td[i]:
+                d.c_touchdown = 0
+            ph["Xbar"] = X0; ph["Ubar"] = np.zeros((h, 24)); ph["uid"] = self.uid[i]
+            phases.append(ph)
+        info = dict(start_times=[float(s) for s in self.start], end_times=[float(e) for e in self.end], horizons=list(self.h), contacts=[np.asarray(c).tolist() for c in self.contact],
+                    shooting=list(self.shooting), has_td=list(self.has_td), x0=phases[0]["Xbar"][0].copy())
+        return phases, info
+
+
+def build_hkd_problem(ref, cpar, plan_duration=0.6, dt_sim=0.01, nsteps_between_mpc=2):
+    """HKDProblem::initialization (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:14-97) at the start of the reference.  Returns (phases, info)."""
+    return HKDProblemData(ref, cpar, plan_duration, dt_sim, nsteps_between_mpc).describe()
 
 
 def hkd_next_footholds(solver, contacts, problem=0):

@@ -864,6 +864,19 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const double* Xbar, const do
     return HSDDP_OK;
 }
 
+int hsddp_set_control_knot(hsddp_handle_t* h, int phase, int k, const double* u) {
+    if (!h || phase < 0 || phase >= h->nph || k < 0 || k >= h->ph[phase].h) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    PhaseDev& P = h->ph[phase]; const size_t pitch = (size_t)P.h * P.m * 8, w = (size_t)P.m * 8;
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (double* dst : {(double*)P.Ubar, (double*)P.U}) {
+        if (u) HIPCK(hipMemcpy2D(dst + (size_t)k * P.m, pitch, u, w, w, h->batch, hipMemcpyHostToDevice));
+        else HIPCK(hipMemset2D(dst + (size_t)k * P.m, pitch, 0, w, h->batch));
+    }
+    h->cache_valid = false;
+    return HSDDP_OK;
+}
+
 // ---- launch helpers
 enum { UNIT_ROLLOUT = 0, UNIT_LQ = 1, UNIT_SWEEP = 2, UNIT_PROBE = 3 };
 static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}; }
@@ -1152,6 +1165,16 @@ int hsddp_export_mpc_command(hsddp_handle_t* h, int problem, int n_steps, double
                        status_times ? h->d_cmd_status : nullptr, h->d_cmd);
     HIPCK(hipMemcpyAsync(out, h->d_cmd, words * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
+    return HSDDP_OK;
+}
+
+int hsddp_export_solver_info(hsddp_handle_t* h, int problem, unsigned int* out) {
+    if (!h || problem < 0 || problem >= h->batch || !out) return HSDDP_EINVAL;
+    HIPCK(hipSetDevice(h->device));
+    ProbState st; HIPCK(hipMemcpy(&st, h->d_st + problem, sizeof(ProbState), hipMemcpyDeviceToHost));
+    const int iv[3] = {st.iter, st.ls_total, st.reg_total};
+    const float fv[5] = {h->solve_ms, (float)st.actual_cost, (float)st.feas, (float)st.info_pconstr, (float)st.info_tconstr};
+    memcpy(out, iv, sizeof(iv)); memcpy(out + 3, fv, sizeof(fv));
     return HSDDP_OK;
 }
 

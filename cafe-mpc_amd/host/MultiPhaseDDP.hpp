@@ -97,6 +97,20 @@ public:
     void warm_start_phase(int dphase, MultiPhaseDDP<T>* prev, int sphase, int popped_front) {
         rc_ = hsddp_warm_start_phase(h_, dphase, prev ? prev->h_ : nullptr, sphase, popped_front);
     }
+    // receding-horizon step INSIDE the handle (what MHPCLocomotion::update gets from MHPCProblem::update + a new solver object,
+    // MHPC/MHPCLocomotion.cpp:102-122): new phase table, trajectories and constraint parameters moved device to device, allocations reused
+    void reconfigure(const std::vector<hsddp_phase_desc_t>& phases_in, const std::vector<int>& src_phase, const std::vector<int>& shift) {
+        n_phases = (int)phases_in.size();
+        rc_ = hsddp_reconfigure(h_, n_phases, phases_in.data(), src_phase.data(), shift.data());
+    }
+    // Trajectory::Ubar[k] written by the caller between solves (HKDProblem::update: Ubar[0].setZero(), HKDProblem.cpp:220); u = nullptr: zeros
+    void set_control_knot(int phase, int k, const T* u = nullptr) { rc_ = hsddp_set_control_knot(h_, phase, k, u); }
+    // solver_info_lcmt (lcmtypes/solver_info_lcmt.lcm) as MHPCLocomotion fills it after a solve (MHPC/MHPCLocomotion.cpp:74-79)
+    struct SolverInfo { int n_iter, n_ls_iter, n_reg_iter; float solve_time, cost, dyn_feas, ineq_violation, eq_violation; };
+    SolverInfo export_solver_info(int problem = 0) {
+        static_assert(sizeof(SolverInfo) == 4 * HSDDP_SOLVER_INFO_WORDS, "solver_info_lcmt: eight 32-bit fields");
+        SolverInfo s{}; rc_ = hsddp_export_solver_info(h_, problem, reinterpret_cast<unsigned int*>(&s)); return s;
+    }
     hsddp_handle_t* handle() { return h_; }
 
 private:

@@ -249,4 +249,92 @@ private:
     }
 };
 
+// ------------------------------------------------------------------------------------------------ HKD-MPC problem
+struct HkdConstraintParams { hsddp_reb_t grf, swing; hsddp_al_t td; };
+inline HkdConstraintParams load_hkd_constraint_params(const std::string& path) {      // loadConstrintParameters (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:66)
+    auto p = load_info(path); HkdConstraintParams c;
+    auto reb = [&](const std::string& n) { auto& m = p[n]; return hsddp_reb_t{std::stod(m["delta"]), std::stod(m["delta_min"]), std::stod(m["eps"])}; };
+    c.grf = reb("GRF_ReB"); c.swing = reb("Swing_ReB");
+    c.td = hsddp_al_t{std::stod(p["TD_AL"]["sigma"]), std::stod(p["TD_AL"]["lambda"]), std::stod(p["TD_AL"]["sigma_max"])};
+    return c;
+}
+
+// Phase table of HKDProblemData + the rules that evolve it: HKDProblem::initialization (HKDProblem.cpp:14-111) with the constants of
+// HKDMPCSolver::initialize (HKDMPC/HKDMPC.cpp:26-29) and the receding-horizon HKDProblem::update (:117-222).  The reference must have been loaded
+// with reorder = true (HKDMPC.h:32).  Same contract as MhpcProblemData: update() returns where every surviving phase's knots come from, the
+// caller hands that to hsddp::MultiPhaseDDP::reconfigure and zeroes the window's first control (set_control_knot(0, 0), HKDProblem.cpp:220).
+class HkdProblemData {
+public:
+    struct Row { float start, end; int h; std::array<int, 4> contact; bool reach_end, has_td; int shooting, uid; };
+    std::vector<Row> ph; float ref_start = 0; int dup_td = 0;
+    HkdProblemData(QuadReference& r, const HkdConstraintParams& p, float plan_duration = 0.6f, float dt_sim = 0.01f, int nsteps_between_mpc = 2)
+        : ref(r), cpar(p), plan(plan_duration), dt(dt_sim), nsteps(nsteps_between_mpc), dt_mpc(dt_sim * (float)nsteps_between_mpc) {
+        ref.initialize(plan);
+        float t = 0, start = 0; auto c_prev = contact_at(t);
+        while (approx_leq(t, plan)) {      // HKDProblem.cpp:34-63
+            auto c_cur = contact_at(t);
+            if (c_cur != c_prev || t > plan || approx_eq(t, plan)) { push(start, t, (int)std::round((float)(t - start) / dt), c_prev, 1); c_prev = c_cur; start = t; }
+            t = t + dt;
+        }
+        for (size_t i = 0; i < ph.size(); i++) ph[i].has_td = touchdown(i);
+    }
+    std::vector<SlotMove> update() {       // HKDProblem::update (:117-222)
+        std::map<int, int> old_h, popped, pushed; for (auto& r : ph) old_h[r.uid] = r.h;
+        for (int j = 0; j < nsteps; j++) {
+            const int adv = ref.step(dt); ref_start = (float)((double)ref_start + adv * (double)ref.dt);
+            const float new_start = ref_start, new_end = new_start + plan;
+            ph.front().start = ph.front().start + dt;
+            if (approx_leq(ph.front().end, new_start)) ph.erase(ph.begin());
+            else { popped[ph.front().uid]++; ph.front().h--; ph.front().start = new_start; }
+            auto nc = contact_at(new_end - new_start); const bool change = nc != ph.back().contact;
+            if (change && ph.back().reach_end) { const float ns = ph.back().end; push(ns, new_end, (int)std::round((float)(new_end - ns) / dt), nc, 0); }
+            else { ph.back().end = new_end; ph.back().h++; if (change) ph.back().reach_end = true; pushed[ph.back().uid]++; }
+            if (ph.back().reach_end) { const bool td = touchdown(ph.size() - 1); if (td && ph.back().has_td) dup_td++; ph.back().has_td = ph.back().has_td || td; }
+        }
+        for (size_t i = 0; i < ph.size(); i++) if (i + 1 < ph.size() || ph[i].h > 2) ph[i].shooting = 1;
+        std::vector<SlotMove> out;
+        for (auto& r : ph) out.push_back({r.uid, popped[r.uid], pushed[r.uid], old_h.count(r.uid) ? old_h[r.uid] : -1});
+        return out;
+    }
+    std::vector<hsddp_phase_desc_t> describe(std::vector<PhaseBuffers>& bufs) const {
+        std::vector<hsddp_phase_desc_t> out; bufs.assign(ph.size(), PhaseBuffers());
+        for (size_t i = 0; i < ph.size(); i++) {
+            const Row& r = ph[i]; const int h = r.h; PhaseBuffers& B = bufs[i];
+            const auto nxt = next_contact(i); const double t_off = (double)(float)(r.start - ph[0].start);
+            B.xr.resize((h + 1) * 24); B.ur.resize((h + 1) * 24); B.foot_pos.resize((h + 1) * 12); B.foot_vel.assign((h + 1) * 12, 0.0); B.body_pos.resize((h + 1) * 3);
+            B.ref_contact.resize((h + 1) * 4); B.Xbar.resize((h + 1) * 24); B.Ubar.assign(h * 24, 0.0);
+            for (int k = 0; k <= h; k++) {
+                const QuadSample& a = ref.at((float)(t_off + k * (double)dt)); hkd_state(a, &B.xr[k * 24]);
+                std::memcpy(&B.ur[k * 24], a.grf, 96); std::memcpy(&B.ur[k * 24 + 12], a.qJd, 96); std::memcpy(&B.foot_pos[k * 12], a.foot_pos, 96);
+                std::memcpy(&B.body_pos[k * 3], a.body, 24); std::memcpy(&B.ref_contact[k * 4], a.contact, 16);
+                hkd_state(ref.at((float)((double)(float)(r.start - ref_start) + k * (double)dt)), &B.Xbar[k * 24]);
+            }
+            hsddp_phase_desc_t d; std::memset(&d, 0, sizeof(d));
+            d.model = HSDDP_MODEL_HKD; d.horizon = h; d.dt = (double)dt; d.t_offset = t_off; d.next_model = HSDDP_MODEL_HKD; d.shooting = r.shooting; d.BG_alpha = 0.0;
+            for (int l = 0; l < 4; l++) { d.contact[l] = r.contact[l]; d.next_contact[l] = nxt[l]; }
+            // HKDTrackingCost weights (HKDCost.h:10-40), terminal weights = 20 x scale x running ones
+            const double q0[12] = {1, 4, 4, 1, 1, 30, 1.0, 0.5, 0.2, 1, 1, 1}, sc[12] = {1, 1, 2, 1, 1, 20, 1.0, 0.2, 0.1, 1, 1, 1};
+            for (int j = 0; j < 12; j++) { d.q[j] = q0[j]; d.qf[j] = 20 * sc[j] * q0[j]; }
+            for (int l = 0; l < 4; l++) for (int j = 0; j < 3; j++) { const double w = 0.1 * (1 - r.contact[l]); d.q[12 + 3 * l + j] = w; d.qf[12 + 3 * l + j] = 20 * 0.01 * w; }
+            for (int j = 0; j < 24; j++) d.r[j] = 0.1;
+            d.w_foot_reg[0] = 100.0; d.w_foot_reg[1] = 100.0; d.w_foot_reg[2] = 0.0; d.w_swing_pos[0] = -1; d.w_swing_vel[0] = -1; d.w_td_vel = -1.0;      // HKDFootPlaceReg (HKDCost.h:55-76)
+            d.c_grf = 1; d.mu = 0.7; d.reb_grf = cpar.grf; d.c_touchdown = r.has_td ? 1 : 0; d.ground_height = 0.0; d.al_td = cpar.td;
+            d.xr = B.xr.data(); d.ur = B.ur.data(); d.foot_pos = B.foot_pos.data(); d.foot_vel = B.foot_vel.data(); d.body_pos = B.body_pos.data(); d.ref_contact = B.ref_contact.data();
+            out.push_back(d);
+        }
+        return out;
+    }
+
+private:
+    QuadReference& ref; HkdConstraintParams cpar; float plan, dt; int nsteps; float dt_mpc; int next_uid = 0;
+    std::array<int, 4> contact_at(float t) const { const QuadSample& s = ref.at(t); return {s.contact[0], s.contact[1], s.contact[2], s.contact[3]}; }
+    void push(float start, float end, int h, const std::array<int, 4>& c, int shooting) { ph.push_back(Row{start, end, h, c, false, false, shooting, next_uid++}); }
+    std::array<int, 4> next_contact(size_t i) const { return i + 1 < ph.size() ? ph[i + 1].contact : contact_at(plan + dt_mpc); }
+    bool touchdown(size_t i) const { const auto n = next_contact(i); for (int l = 0; l < 4; l++) if (ph[i].contact[l] == 0 && n[l] == 1) return true; return false; }
+    static void hkd_state(const QuadSample& a, double* x) {      // HKDSinglePhaseReference::get_reference_at_t (HKDReference.cpp:23-61): [eul, pos, omega, v, qdummy]
+        for (int i = 0; i < 3; i++) { x[i] = a.body[3 + i]; x[3 + i] = a.body[i]; x[6 + i] = a.body[9 + i]; x[9 + i] = a.body[6 + i]; }
+        for (int l = 0; l < 4; l++) for (int j = 0; j < 3; j++) x[12 + 3 * l + j] = a.contact[l] > 0 ? a.foot_pos[3 * l + j] : a.qJ[3 * l + j];
+    }
+};
+
 }  // namespace hsddp

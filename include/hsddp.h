@@ -150,6 +150,11 @@ int hsddp_set_initial_condition(hsddp_handle_t *h, const double *x0);
  * per_problem=0 broadcasts one trajectory to the whole batch. Also zeroes K, dU, dX like a fresh Trajectory. */
 int hsddp_set_nominal(hsddp_handle_t *h, int phase, const double *Xbar, const double *Ubar, int per_problem);
 
+/* -- one control knot of the nominal trajectory, what a caller writes into Trajectory::Ubar[k] between solves: HKDProblem::update ends with
+ * trajectory_ptrs.front()->Ubar[0].setZero() (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:220).  u: batch x m, or NULL for zeros.  Ubar[k] and U[k]
+ * are set; everything else of the trajectory stays. */
+int hsddp_set_control_knot(hsddp_handle_t *h, int phase, int k, const double *u);
+
 /* -- MultiPhaseDDP::solve (MultiPhaseDDP.cpp:216-447).  max_cputime_ms as in the reference.  opt->MS = 0: single shooting over the whole
  * horizon (MultiPhaseDDP.cpp:65-68: no shooting nodes, no defects, no linear rollout; dV from the backward sweep). */
 int hsddp_solve(hsddp_handle_t *h, const hsddp_option_t *opt, float max_cputime_ms);
@@ -218,6 +223,12 @@ int hsddp_reconfigure(hsddp_handle_t *h, int n_phases, const hsddp_phase_desc_t 
 #define HSDDP_CMD_WORDS_PER_STEP 1089
 int hsddp_export_mpc_command(hsddp_handle_t *h, int problem, int n_steps, double mpc_time, double dt, const float *status_times,
                              unsigned int *out /* 1 + n_steps*HSDDP_CMD_WORDS_PER_STEP words */);
+
+/* -- lcmtypes/solver_info_lcmt.lcm as MHPCLocomotion fills it after every solve (MHPC/MHPCLocomotion.cpp:74-79, 127-131): eight 32-bit words
+ * in field order  int32 n_iter | int32 n_ls_iter | int32 n_reg_iter | float solve_time (ms) | float cost | float dyn_feas |
+ * float ineq_violation (get_path_constraint_violation) | float eq_violation (get_terminal_constraint_violation)  of one problem. */
+#define HSDDP_SOLVER_INFO_WORDS 8
+int hsddp_export_solver_info(hsddp_handle_t *h, int problem, unsigned int *out /* HSDDP_SOLVER_INFO_WORDS words */);
 
 const char *hsddp_backend_name(void); /* "hip-gfx950" or "cpu-oracle" */
 

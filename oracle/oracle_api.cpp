@@ -65,6 +65,15 @@ int hsddp_set_nominal(hsddp_handle_t* h, int phase, const abi_f64* Xbar, const a
     }
     return HSDDP_OK;
 }
+int hsddp_set_control_knot(hsddp_handle_t* h, int phase, int k, const abi_f64* u) {      // Trajectory::Ubar[k] written by the caller (HKDProblem.cpp:220)
+    if (!h || phase < 0 || phase >= (int)h->s.ph.size() || k < 0 || k >= h->s.ph[phase].h) return HSDDP_EINVAL;
+    const int m = h->s.ph[phase].m;
+    for (int b = 0; b < h->s.batch; b++) {
+        Traj& T = h->s.pb[b].tr[phase];
+        for (int i = 0; i < m; i++) { const abi_f64 v = u ? u[(size_t)b * m + i] : 0; T.Ubar[(size_t)k * m + i] = v; T.U[(size_t)k * m + i] = v; }
+    }
+    return HSDDP_OK;
+}
 int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_ms) {
     if (!h || !opt) return HSDDP_EINVAL;
     h->s.solve(*opt, max_cputime_ms); return HSDDP_OK;
@@ -149,6 +158,16 @@ int hsddp_get_field(hsddp_handle_t* h, int phase, int field, int b0, int nb, abi
     return 0;
 }
 float hsddp_get_solve_time_ms(hsddp_handle_t* h) { return h->s.solve_ms; }
+// solver_info_lcmt as MHPCLocomotion fills it (MHPC/MHPCLocomotion.cpp:74-79)
+int hsddp_export_solver_info(hsddp_handle_t* h, int problem, unsigned int* out) {
+    if (!h || problem < 0 || problem >= h->s.batch || !out) return HSDDP_EINVAL;
+    hsddp_info_t info[1]; const Problem& q = h->s.pb[problem];
+    const int iv[3] = {q.iter_, q.ls_iter_total_, q.reg_iter_total_};
+    const float fv[5] = {h->s.solve_ms, (float)q.actual_cost, (float)q.feas, (float)(q.ineq_feas_buffer.empty() ? q.max_pconstr : q.ineq_feas_buffer.back()),
+                         (float)(q.eqn_feas_buffer.empty() ? q.max_tconstr : q.eqn_feas_buffer.back())};
+    (void)info; std::memcpy(out, iv, sizeof(iv)); std::memcpy(out + 3, fv, sizeof(fv));
+    return HSDDP_OK;
+}
 // SinglePhase::pop_front x shift + push_back_default for the rest (SinglePhase.cpp:513-528, TrajectoryManagement.cpp:130-228); the ReB parameters
 // travel with their knots and a pushed knot copies the last knot's (PathConstraintBase::pop_front / push_back, ConstraintsBase.h:296-306;
 // reset_params() is a no-op, :192), the AL parameters of the terminal constraint stay with the phase (:375)

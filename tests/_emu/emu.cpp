@@ -206,6 +206,8 @@ float hsddp_get_solve_time_ms(hsddp_handle_t*) { return 0; }
 int hsddp_export_mpc_command(hsddp_handle_t*, int, int, double, double, const float*, unsigned int*) { return HSDDP_ENOTSUP; }
 int hsddp_warm_start_phase(hsddp_handle_t*, int, hsddp_handle_t*, int, int) { return HSDDP_ENOTSUP; }
 int hsddp_reconfigure(hsddp_handle_t*, int, const hsddp_phase_desc_t*, const int*, const int*) { return HSDDP_ENOTSUP; }
+int hsddp_set_control_knot(hsddp_handle_t*, int, int, const double*) { return HSDDP_ENOTSUP; }
+int hsddp_export_solver_info(hsddp_handle_t*, int, unsigned int*) { return HSDDP_ENOTSUP; }
 int hsddp_get_kernel_times(hsddp_handle_t*, int, double*, long long*, char*, int) { return 0; }
 int hsddp_get_kernel_units(hsddp_handle_t*, const char*, long long*) { return HSDDP_ENOTSUP; }
 int hsddp_reset_kernel_times(hsddp_handle_t*) { return 0; }

@@ -11,6 +11,33 @@ static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull
 int main(int argc, char** argv) {
     if (argc < 4) return 2;
     const std::string root = argv[1], gait = argv[2]; const int nticks = std::atoi(argv[3]);
+    const bool hkd = argc > 4 && std::string(argv[4]) == "hkd";      // the HKD-MPC problem (HkdProblemData) instead of the MHPC one
+    auto dump = [&](const std::vector<hsddp_phase_desc_t>& descs, const std::vector<hsddp::PhaseBuffers>& bufs) {
+        std::cout << "[";
+        for (size_t i = 0; i < descs.size(); i++) {
+            const auto& d = descs[i]; const auto& B = bufs[i];
+            uint64_t h = fnv(B.xr.data(), B.xr.size() * 8); h = fnv(B.ur.data(), B.ur.size() * 8, h); h = fnv(B.yr.data(), B.yr.size() * 8, h);
+            h = fnv(B.foot_pos.data(), B.foot_pos.size() * 8, h); h = fnv(B.foot_vel.data(), B.foot_vel.size() * 8, h); h = fnv(B.body_pos.data(), B.body_pos.size() * 8, h);
+            h = fnv(B.ref_contact.data(), B.ref_contact.size() * 4, h); h = fnv(B.Xbar.data(), B.Xbar.size() * 8, h);
+            uint64_t w = fnv(d.q, sizeof(d.q)); w = fnv(d.r, sizeof(d.r), w); w = fnv(d.qf, sizeof(d.qf), w); w = fnv(&d.reb_torque, sizeof(hsddp_reb_t) * 4, w); w = fnv(&d.al_td, sizeof(d.al_td), w);
+            std::cout << (i ? "," : "") << "{\"model\":" << d.model << ",\"h\":" << d.horizon << ",\"dt\":" << d.dt << ",\"t_offset\":" << d.t_offset
+                      << ",\"contact\":[" << d.contact[0] << "," << d.contact[1] << "," << d.contact[2] << "," << d.contact[3] << "],\"next_contact\":[" << d.next_contact[0] << ","
+                      << d.next_contact[1] << "," << d.next_contact[2] << "," << d.next_contact[3] << "],\"next_model\":" << d.next_model << ",\"shooting\":" << d.shooting
+                      << ",\"c_touchdown\":" << d.c_touchdown << ",\"w_td_vel\":" << d.w_td_vel << ",\"hash\":\"" << h << "\",\"whash\":\"" << w << "\"}";
+        }
+        std::cout << "]";
+    };
+    if (hkd) {
+        hsddp::QuadReference ref; if (!ref.load(root + "/Reference/Data/" + gait + "/quad_reference.csv", true)) return 3;
+        hsddp::HkdProblemData pd(ref, hsddp::load_hkd_constraint_params(root + "/HKDMPC/settings/constraint_params.info"));
+        std::cout << "[";
+        for (int tick = 0; tick <= nticks; tick++) {
+            if (tick > 0) { pd.update(); std::cout << ","; }
+            std::vector<hsddp::PhaseBuffers> bufs; auto descs = pd.describe(bufs); dump(descs, bufs);
+        }
+        std::cout << "]\n";
+        return 0;
+    }
     auto cfg = hsddp::load_mhpc_config(root + "/MHPC/settings/mhpc_config.info");
     auto costs = hsddp::load_cost_weights(root + "/" + cfg.costFile);
     auto cpar = hsddp::load_constraint_params(root + "/" + cfg.constraintParamFile);

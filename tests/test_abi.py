@@ -96,3 +96,23 @@ def test_cpp_host_mirror_runs_end_to_end(oracle_lib, tmp_path):
     assert np.array_equal(np.array(out["history_cost"], dtype=np.float32), hst["cost"])
     # one entry after the initial rollout + one per inner iteration that ran to its last line (MultiPhaseDDP.cpp:258-261, 382-385): at most n_iters + 1
     assert 2 <= len(hst["cost"]) <= out["n_iters"] + 1
+
+
+def test_cpp_mpc_loop_harness_matches_the_python_path(oracle_lib, tmp_path):
+    """tests/cpp/mpc_loop.cpp - the receding-horizon loop of MHPCLocomotion::update / testTrajOptInLoop.cpp on the C++ host path (C++ problem
+    builder update + describe, hsddp::MultiPhaseDDP reconfigure / solve / export_mpc_command / export_solver_info) - executed here against the CPU
+    checker library for 6 ticks, against the same loop through ctypes: same iterations and costs every tick.  (-m gpu runs it on libhsddp_hip.so.)"""
+    import json
+    import parity_common as pc
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    exe = tmp_path / "mpc_loop"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "mpc_loop.cpp"), "-L", os.path.join(ROOT, "oracle"), "-loracle_hsddp", "-fopenmp",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-o", str(exe)])
+    opt0, iters, cost = pc.python_mpc_loop(pkg, oracle_lib, tree, 6)
+    (tmp_path / "opt.bin").write_bytes(bytes(opt0))
+    out = json.loads(subprocess.check_output([str(exe), tree, "bound", str(tmp_path / "opt.bin"), "6", "0"], timeout=600))
+    assert out["iters"] == iters and out["status"] == [0] * 6
+    import numpy as np
+    assert np.allclose(out["cost"], cost, rtol=1e-12)
+    assert out["total_ms_mean"] > 0 and out["descriptor_build_ms_mean"] > 0

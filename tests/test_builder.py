@@ -124,6 +124,59 @@ def test_cpp_builder_matches_python_mirror(tmp_path, gait):
             assert str(_fnv(wb)) == c["whash"]
 
 
+def test_hkd_receding_horizon_update_rules(oracle_lib, tmp_path):
+    """HKDProblem::update (HKDMPC/HKD-TrajOpt/HKDProblem.cpp:117-222) over 30 MPC ticks of the shipped bound gait: the window keeps its 60 knots, a
+    contact change at the horizon end first grows the last phase and then appends a young phase that has no shooting nodes until it is longer
+    than two knots (:211-216), touchdown constraints appear when a phase's end has been seen (:201-204), no phase gets the constraint twice on
+    this gait.  The C++ builder (host/mhpc_builder.hpp HkdProblemData) emits the same descriptors bit for bit.  The MPC loop of
+    HKDMPC.cpp:97-143 (2 AL x 1 DDP per tick, window moved inside the handle, first control zeroed) runs on the oracle."""
+    import json, subprocess, ctypes
+    exe = tmp_path / "builder_dump"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "builder_dump.cpp"), "-o", str(exe)])
+    nticks = 30
+    cpp = json.loads(subprocess.check_output([str(exe), TREE, "bound", str(nticks), "hkd"]))
+    ref = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"), reorder=True)
+    pd = builder.HKDProblemData(ref, builder.load_hkd_constraint_params(os.path.join(TREE, "HKDMPC/settings/constraint_params.info")))
+    young = 0
+    for tick in range(nticks + 1):
+        if tick:
+            m = pd.update()
+            assert all(v[0] in (0, 1, 2) and v[1] in (0, 1, 2) for v in m.values())
+        phases, info = pd.describe()
+        assert sum(info["horizons"]) == 60 and len(phases) == len(cpp[tick])
+        assert all(s == 1 for s in info["shooting"][:-1]) and (info["shooting"][-1] == 1) == (info["horizons"][-1] > 2 or tick == 0)
+        young += info["shooting"][-1] == 0
+        for p, c in zip(phases, cpp[tick]):
+            d, B = p["desc"], p["bufs"]
+            assert (d.model, d.horizon, d.shooting, d.c_touchdown, d.next_model) == (c["model"], c["h"], c["shooting"], c["c_touchdown"], c["next_model"])
+            assert list(d.contact) == c["contact"] and list(d.next_contact) == c["next_contact"] and abs(d.t_offset - c["t_offset"]) < 1e-6
+            arrays = [B["xr"], B["ur"], np.zeros(0), B["foot_pos"], B["foot_vel"], B["body_pos"], B["ref_contact"], p["Xbar"]]
+            assert str(_fnv(np.ascontiguousarray(a).tobytes() for a in arrays)) == c["hash"], (tick, d.horizon)
+            wb = [bytes(d.q), bytes(d.r), bytes(d.qf), ctypes.string_at(ctypes.addressof(d.reb_torque), 4 * ctypes.sizeof(d.reb_torque)), bytes(d.al_td)]
+            assert str(_fnv(wb)) == c["whash"]
+    assert young >= 5 and pd.dup_td == 0
+    # the loop on the oracle
+    ref = builder.QuadReference(os.path.join(TREE, "Reference/Data/bound/quad_reference.csv"), reorder=True)
+    pd = builder.HKDProblemData(ref, builder.load_hkd_constraint_params(os.path.join(TREE, "HKDMPC/settings/constraint_params.info")))
+    opt0 = builder.load_ddp_setting(os.path.join(TREE, "HKDMPC/settings/ddp_setting.info")); opt0.max_AL_iter, opt0.max_DDP_iter = 2, 4
+    opt_rt = builder.load_ddp_setting(os.path.join(TREE, "HKDMPC/settings/ddp_setting.info")); opt_rt.max_AL_iter, opt_rt.max_DDP_iter = 2, 1      # HKDMPC.cpp:102-103
+    phases, info = pd.describe()
+    s = pc.make_pair(pkg, oracle_lib, oracle_lib, phases, info["x0"][None])[0]
+    s.solve(opt0)
+    for tick in range(1, 7):
+        m = pd.update(); old = phases
+        phases, inf = builder.shift_solver_in_place(s, old, pd, m)
+        assert np.abs(s.field(0, "UBAR")[:, 0]).max() > 0
+        s.set_control_knot(0, 0, None)
+        assert np.abs(s.field(0, "UBAR")[:, 0]).max() == 0 and np.abs(s.field(0, "UBAR")[:, 1]).max() > 0
+        s.set_initial_condition(np.ascontiguousarray(s.field(0, "XBAR")[:, 0])); s.solve(opt_rt)
+        ia = s.info_arrays()
+        assert ia["status"][0] == 0 and ia["n_iters"][0] == 2 and np.isfinite(ia["actual_cost"][0])
+        si = s.export_solver_info(0)
+        assert (si["n_iter"], si["n_ls_iter"]) == (ia["n_iters"][0], ia["n_ls_iters"][0]) and si["cost"] == np.float32(ia["actual_cost"][0]) and si["eq_violation"] == np.float32(ia["max_tconstr"][0])
+
+
 def _mpc_setup():
     cfg = builder.load_mhpc_config(TREE + "/MHPC/settings/mhpc_config.info")
     pd = builder.MHPCProblemData(builder.QuadReference(TREE + "/Reference/Data/bound/quad_reference.csv"), cfg,

@@ -201,6 +201,46 @@ def test_receding_horizon_loop_parity(hip_lib, oracle_lib):
     assert mallocs[3:] == [mallocs[3]] * len(mallocs[3:]), mallocs     # a warm handle runs its ticks without device allocations
 
 
+def test_hkd_receding_horizon_loop_parity(hip_lib, oracle_lib):
+    """The HKD-MPC loop of HKDMPC.cpp:97-143 on the shipped bound gait: initial solve, then per tick HKDProblem::update (builder.HKDProblemData: front
+    pop / back grow, young last phases without shooting nodes, touchdown constraints once a phase's end has been seen) moved inside the handle
+    (hsddp_reconfigure), the window's first control zeroed (HKDProblem.cpp:220 -> hsddp_set_control_knot), 2 AL x 1 DDP iterations (:102-103),
+    foot placements extracted (HKDMPC.cpp:207-240).  GPU and oracle run the same loop for 10 ticks; every tick's solve must agree, the
+    footholds too, and a warm handle must not allocate."""
+    import importlib
+    builder = importlib.import_module(pkg.__name__ + ".builder")
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    cp = builder.load_hkd_constraint_params(os.path.join(tree, "HKDMPC/settings/constraint_params.info"))
+    pds = [builder.HKDProblemData(builder.QuadReference(os.path.join(tree, "Reference/Data/bound/quad_reference.csv"), reorder=True), cp) for _ in range(2)]      # one table per backend (same rules, same data)
+    opt0 = builder.load_ddp_setting(os.path.join(tree, "HKDMPC/settings/ddp_setting.info")); opt0.max_AL_iter, opt0.max_DDP_iter = 2, 4
+    opt_rt = builder.load_ddp_setting(os.path.join(tree, "HKDMPC/settings/ddp_setting.info")); opt_rt.max_AL_iter, opt_rt.max_DDP_iter = 2, 1
+    phases, info = pds[0].describe(); pds[1].describe()
+    x0 = np.vstack([info["x0"], info["x0"]]); x0[1, :12] += 0.01
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    so.solve(opt0); sg.solve(opt0)
+    pc.compare_solve(so, sg, len(phases))
+    seen_young = seen_pop = False
+    mallocs = []
+    ph = [phases, phases]
+    for tick in range(1, 11):
+        for j, s_ in enumerate((so, sg)):
+            m = pds[j].update()
+            ph[j], inf = builder.shift_solver_in_place(s_, ph[j], pds[j], m)
+            s_.set_control_knot(0, 0, None)
+        seen_young |= 0 in inf["shooting"]; seen_pop |= len(ph[1]) != len(phases)
+        assert sum(inf["horizons"]) == 60
+        x0n = np.ascontiguousarray(sg.field(0, "XBAR")[:, 0])      # the shifted plan's first state = next initial condition (same vector for both backends)
+        for s_ in (so, sg):
+            s_.set_initial_condition(x0n); s_.solve(opt_rt)
+        pc.compare_solve(so, sg, len(ph[1]), tag=f"hkd tick {tick}")
+        pf_o, pf_g = builder.hkd_next_footholds(so, inf["contacts"]), builder.hkd_next_footholds(sg, inf["contacts"])
+        assert set(pf_g) == set(pf_o) and all(np.allclose(pf_g[l], pf_o[l], atol=1e-6) for l in pf_g)
+        assert sg.export_solver_info(0)["n_iter"] == sg.info_arrays()["n_iters"][0] == 2
+        mallocs.append(hip_lib.hsddp_debug_malloc_count())
+    assert seen_young and seen_pop
+    assert mallocs[4:] == [mallocs[4]] * len(mallocs[4:]), mallocs
+
+
 def test_full_solve_parity_barrel_roll(hip_lib, oracle_lib, oracle_ld_lib):
     """BarrelRollTO.cpp as shipped: 6 hybrid phases / 125 knots (stance, right-side stance, flight, landing, flight, stance),
     zero-torque start, br_ddp_setting.info; the first AL iteration (10 DDP iterations, line searches down to small steps)."""
@@ -416,6 +456,26 @@ def test_cpp_host_mirror_against_the_hip_library(hip_lib, tmp_path):
     assert np.array_equal(np.array(out["k0"]), s.field(0, "K")[0, 0].T.ravel())
     hst = s.get_history(0)
     assert np.array_equal(np.array(out["history_cost"], dtype=np.float32), hst["cost"]) and len(hst["cost"]) >= 2
+
+
+def test_cpp_mpc_loop_on_the_hip_library(hip_lib, tmp_path):
+    """The 18 ms story on the reference-shaped C++ path: tests/cpp/mpc_loop.cpp linked against libhsddp_hip.so runs 24 receding-horizon ticks (C++
+    builder update + describe + reconfigure + set_initial_condition + solve(opt, 0.9 dt_mpc) + command and solver-info export), every tick inside
+    the reference's budget INCLUDING the descriptor building, no device allocation once warm; iterations and costs equal the ctypes path's."""
+    import subprocess
+    tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
+    exe = tmp_path / "mpc_loop"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cafe-mpc_amd", "host"),
+                           os.path.join(ROOT, "tests", "cpp", "mpc_loop.cpp"), "-L", os.path.join(ROOT, "cafe-mpc_amd"), "-lhsddp_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "cafe-mpc_amd"), "-o", str(exe)])
+    opt0, iters, cost = pc.python_mpc_loop(pkg, hip_lib, tree, 24)
+    (tmp_path / "opt.bin").write_bytes(bytes(opt0))
+    out = json.loads(subprocess.check_output([str(exe), tree, "bound", str(tmp_path / "opt.bin"), "24"], timeout=300))
+    print("C++ MPC loop:", {k: v for k, v in out.items() if k.endswith(("_mean", "_max"))})
+    assert out["status"] == [0] * 24 and out["iters"] == iters
+    assert np.allclose(out["cost"], cost, rtol=1e-9)
+    assert out["device_allocations_in_warm_ticks"] == 0
+    assert out["total_ms_max"] < out["budget_ms"] * 0.9, out      # every warm tick inside 0.9 dt_mpc = 18 ms, host work included
 
 
 def test_history_buffers_parity(hip_lib, oracle_lib):
