@@ -417,6 +417,20 @@ __global__ void __launch_bounds__(256) k_pack_command(const PhaseDev* ph, const 
     }
 }
 
+// K dX of every whole-body control knot from the CURRENT gains (step API: a backward sweep without the linear rollout behind it leaves new gains
+// next to the old search direction dX; SinglePhase::hybrid_rollout would apply the new K to it, SinglePhase.cpp:196-200)
+__global__ void __launch_bounds__(64) k_refresh_kdx(const PhaseDev* ph, int nph) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int pi = 0; pi < nph; pi++) {
+        const PhaseDev& P = ph[pi];
+        if (P.model != HSDDP_MODEL_WB) continue;
+        for (int k = blockIdx.x; k < P.h; k += gridDim.x) {
+            const size_t kk = (size_t)b * P.h + k, kx = ((size_t)b * (P.h + 1) + k) * 36;
+            if (tid < 12) { double s = 0; for (int j = 0; j < 36; j++) s += P.K[kk * 432 + tid + 12 * j] * P.dX[kx + j]; P.KdX[kk * 12 + tid] = s; }
+        }
+    }
+}
+
 // X -> Xbar, U -> Ubar, Defect -> Defect_bar (Trajectory::update_nominal_vals, TrajectoryManagement.cpp:122-127)
 __global__ void k_update_nominal(const PhaseDev* ph, int nph, const ProbState* st, int mask) {
     const int b = blockIdx.y;
@@ -1047,6 +1061,7 @@ int hsddp_LQ_approximation(hsddp_handle_t* h, const hsddp_option_t* opt) {
 int hsddp_backward_sweep(hsddp_handle_t* h, double regularization, int* success) {
     if (!h) return HSDDP_EINVAL; HIPCK(hipSetDevice(h->device)); OptDev o{};
     launch_sweep(h, o, MASK_NONE, regularization, 0, 0, 0.0, h->d_success);
+    if (!h->has_hkd && !h->f32) hipLaunchKernelGGL(k_refresh_kdx, dim3(64, h->batch), dim3(64), 0, h->stream, h->d_ph, h->nph);      // the new gains on the standing search direction
     HIPCK(hipStreamSynchronize(h->stream)); drain_events(h); HIPCK(hipGetLastError());
     if (success) HIPCK(hipMemcpy(success, h->d_success, h->batch * sizeof(int), hipMemcpyDeviceToHost));
     return HSDDP_OK;

@@ -612,6 +612,101 @@ def test_fp32_handle_kinodynamic_parity_with_measured_tolerance(hip_lib, oracle_
         pkg.Solver(hip_lib, pkg.problems.wb_stance_problem(horizon=3), batch=1, precision=pkg.PREC_F32)      # whole-body phases need fp64
 
 
+def _fp32_errors(so, sg, nph, fields=("XBAR", "UBAR", "K")):
+    out = {}
+    for f in fields:
+        e = sc = 0.0
+        for i in range(nph):
+            a, b = so.field(i, f), sg.field(i, f)
+            if a.size:
+                e = max(e, float(np.abs(a - b).max())); sc = max(sc, float(np.abs(a).max()))
+        out[f] = (e, max(sc, 1.0))
+    return out
+
+
+def test_config5_hkd_bound_batch_16384_fp32(hip_lib, oracle_lib):
+    """BASELINE config 5 at its own workload: the kinodynamic model (24/24/0) over N = 200 knots in the contact pattern of the shipped bound gait
+    (21 phases: 1111(6), then 1100(10) 0000(10) 0011(10) 0000(10) repeating), an ensemble of 16 384 initial states on an fp32 handle (fp32 LQ
+    records, Riccati sweep + linear rollout on v_mfma_f32_16x16x4_f32), fixed-work mode, five iterations: every problem ends with status 0 after
+    exactly five iterations, duplicated initial states give bit-identical results wherever they sit in the batch, and six sampled problems agree
+    with the fp64 oracle at the fp32 error level measured for this workload (x ~3; the reference is double only - north_star's 1e-6 on K does not
+    apply to an fp32 handle).  Measured (gpurun_out/r03i): cost 5e-8 relative, XBAR 6.2e-4, UBAR 5.5e-5, K 2.5e-3 of their scales (|K| = 1 400)."""
+    B = 16384
+    phases = pkg.problems.hkd_bound_problem()
+    assert len(phases) == 21 and sum(p["desc"].horizon for p in phases) == 200
+    x0 = pkg.problems.hkd_ensemble_x0(B, 20241220 + 5, phases)          # the ensemble bench.py --hkd draws
+    x0[B - 1] = x0[0]; x0[B // 2 + 3] = x0[7]
+    opt = pkg.problems.hkd_ddp_setting(max_AL_iter=1, max_DDP_iter=5, cost_thresh=0.0)
+    s = pkg.MultiPhaseDDP(phases, batch=B, precision=pkg.PREC_F32)
+    assert hip_lib.hsddp_precision(s.h) == pkg.PREC_F32
+    s.set_initial_condition(x0); s.solve(opt)
+    ia = s.info_arrays()
+    assert (ia["status"] == 0).all() and (ia["n_iters"] == 5).all() and np.isfinite(ia["actual_cost"]).all()
+    for f in ("XBAR", "UBAR", "K"):
+        for i in (0, 10, 20):
+            assert np.array_equal(s.field(i, f, 0, 1), s.field(i, f, B - 1, 1)) and np.array_equal(s.field(i, f, 7, 1), s.field(i, f, B // 2 + 3, 1))
+    idx = [0, 7, 1023, 5000, 12000, B - 2]
+    so = pkg.Solver(oracle_lib, phases, batch=len(idx))
+    for i, p in enumerate(phases):
+        so.set_nominal(i, p["Xbar"], p["Ubar"])
+    so.set_initial_condition(np.ascontiguousarray(x0[idx])); so.solve(opt)
+    io = so.info_arrays(); sub = _Sub(s, idx); ig = sub.info_arrays()
+    assert np.array_equal(io["n_iters"], ig["n_iters"]) and np.array_equal(io["status"], ig["status"])
+    rel_cost = float(np.max(np.abs(io["actual_cost"] - ig["actual_cost"]) / np.abs(io["actual_cost"])))
+    err = _fp32_errors(so, sub, len(phases))
+    print("config 5 fp32 vs fp64 oracle: rel cost", rel_cost, {k: (v[0], v[1]) for k, v in err.items()}, "ls trials", io["n_ls_iters"], ig["n_ls_iters"])
+    assert rel_cost < 5e-7, rel_cost
+    assert err["XBAR"][0] <= 2e-3 * err["XBAR"][1] and err["UBAR"][0] <= 2e-4 * err["UBAR"][1] and err["K"][0] <= 8e-3 * err["K"][1], err
+    s.close()
+
+
+def test_fp32_handle_single_rigid_body_phases(hip_lib, oracle_lib):
+    """HSDDP_PREC_F32 on single-rigid-body phases alone (the other model set of fp32 handles: SinglePhase.cpp:566; k_rollout / k_lq write the
+    fp32 record through rec_put, k_sweep32 runs riccati_phase / linear_phase <12,12,0,float>): per iterate and full solve against the fp64
+    oracle at the fp32 error level measured for this problem (x ~3)."""
+    phases = pkg.problems.mhpc_problem(wb_schedule=(), wb_horizons=(), srb_horizons=(8, 7))
+    x0 = _srb_x0(pkg.problems.wb_ensemble_x0(3, 20241230))
+    opt = pkg.mhpc_ddp_setting()
+    so = pkg.Solver(oracle_lib, phases, batch=3); sg = pkg.Solver(hip_lib, phases, batch=3, precision=pkg.PREC_F32)
+    assert hip_lib.hsddp_precision(sg.h) == pkg.PREC_F32
+    for s_ in (so, sg):
+        for i, p in enumerate(phases):
+            s_.set_nominal(i, p["Xbar"], p["Ubar"])
+        s_.set_initial_condition(x0)
+    worst = {}
+    for it in range(3):
+        eps = 0.0 if it == 0 else 1.0
+        for s_ in (so, sg):
+            s_.hybrid_rollout(eps, opt); s_.compute_cost(opt)
+            if it == 0:
+                s_.update_nominal_trajectory()
+            s_.LQ_approximation(opt)
+            assert s_.backward_sweep(0.0).all()
+        da, db = so.get_exp_cost_change(), sg.get_exp_cost_change()
+        assert np.allclose(da[0], db[0], rtol=2e-3, atol=1e-3) and np.allclose(da[1], db[1], rtol=2e-3), (da, db)
+        for s_ in (so, sg):
+            s_.linear_rollout(1.0, opt)
+        for f in ("A", "B", "LXX", "LUU", "K", "DU", "DX", "X", "U"):
+            for i in range(len(phases)):
+                a, b = so.field(i, f), sg.field(i, f)
+                if a.size:
+                    worst[f] = max(worst.get(f, 0.0), float(np.abs(a - b).max() / max(1.0, np.abs(a).max())))
+    print("fp32 SRB per-iterate relative errors:", worst)
+    lim = {"A": 3e-5, "B": 6e-6, "LXX": 4e-6, "LUU": 1e-6, "K": 1e-4, "DU": 1.2e-4, "DX": 1e-3, "X": 3e-4, "U": 3e-5}      # measured (gpurun_out/r03i) x ~3
+    assert all(worst[f] <= lim[f] for f in lim), worst
+    so.close(); sg.close()
+    so = pkg.Solver(oracle_lib, phases, batch=3); sg = pkg.Solver(hip_lib, phases, batch=3, precision=pkg.PREC_F32)
+    o2 = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=4)
+    for s_ in (so, sg):
+        for i, p in enumerate(phases):
+            s_.set_nominal(i, p["Xbar"], p["Ubar"])
+        s_.set_initial_condition(x0); s_.solve(o2)
+    ia, ib = so.info_arrays(), sg.info_arrays()
+    assert (ib["status"] == 0).all() and np.allclose(ia["actual_cost"], ib["actual_cost"], rtol=2e-3), (ia["actual_cost"], ib["actual_cost"])
+    e = _fp32_errors(so, sg, len(phases), ("XBAR",))
+    assert e["XBAR"][0] <= 2e-2 * e["XBAR"][1], e
+
+
 def test_flight_phase_and_four_foot_touchdown(hip_lib, oracle_lib):
     """Barrel-roll-like schedule (BarrelRollTO.cpp:70-81 shape): stance -> flight (no contact: free-fall dynamics,
     no GRF constraints) -> stance, i.e. a four-foot touchdown (12-row impulse, the mis-sliced impulse of quirk v)."""
@@ -707,6 +802,24 @@ def test_lq_without_a_preceding_rollout(hip_lib, oracle_lib):
     for s_ in (so, sg):                       # and the cached path right after, on the same state
         s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.LQ_approximation(opt)     # compute_cost zeroes the oracle's cost partials (quirk ii)
     pc.compare(so, sg, pc.STEP_FIELDS["lq"], len(phases), 1e-8, "lq_cached")
+
+
+def test_step_api_sweep_then_rollout_uses_the_new_gains(hip_lib, oracle_lib):
+    """Public step methods in an order solve() never takes: backward_sweep, then hybrid_rollout(eps) WITHOUT a linear rollout in between.  The
+    reference applies the new gains to the standing search direction, u = ubar + eps dU + K (x - xbar) (SinglePhase.cpp:196-200); the whole-body
+    rollout knots take K dX from a 12-vector the linear rollout normally leaves behind, so the sweep of the step API refreshes it."""
+    phases = pkg.problems.wb_trot_problem(horizons=(6, 5, 5, 6))
+    x0 = pkg.problems.wb_ensemble_x0(3, 20241229)
+    so, sg = pc.make_pair(pkg, oracle_lib, hip_lib, phases, x0)
+    opt = pkg.mhpc_ddp_setting()
+    for s_ in (so, sg):
+        s_.hybrid_rollout(0.0, opt); s_.compute_cost(opt); s_.update_nominal_trajectory(); s_.LQ_approximation(opt)
+        assert s_.backward_sweep(0.0).all(); s_.linear_rollout(1.0, opt)            # a search direction dX
+        s_.hybrid_rollout(1.0, opt); s_.compute_cost(opt); s_.LQ_approximation(opt)    # new LQ model at the trial point (nominal unchanged)
+        assert s_.backward_sweep(0.0).all()                                          # new gains, old dX: no linear rollout
+        s_.hybrid_rollout(0.5, opt); s_.compute_cost(opt)
+    pc.compare(so, sg, pc.STEP_FIELDS["rollout"], len(phases), 1e-8, "sweep_then_rollout")
+    assert np.abs(so.field(0, "U") - so.field(0, "UBAR")).max() > 1e-3
 
 
 def test_unsupported_configurations_fail_loudly(hip_lib):

@@ -8,6 +8,7 @@ import __graft_entry__ as ge  # noqa: E402
 SRC_HASH = ge.load_package().kernel_source_hash()
 tag = sys.argv[1]
 out = f"gpurun_out/{tag}"
+HKD = sys.argv[2] if len(sys.argv) > 2 else None      # "hkdf32" / "hkdf64": the config-5 outputs of tools/profile_hkd.sh instead of the whole-body ones
 
 
 def find(pattern):
@@ -24,12 +25,20 @@ def last_json_line(path):
     return None
 
 
-st = find("stats/**/*kernel_stats.csv")
-if st:
-    shutil.copy(st, f"profiles/{tag}_kernel_stats_batch4096_steps20.csv")
-for n in ("steps20", "steps10"):
-    if os.path.exists(f"{out}/bench_{n}.json"):
-        shutil.copy(f"{out}/bench_{n}.json", f"profiles/{tag}_bench_batch4096_{n}.json")
+if HKD:
+    st = find(f"{HKD}_stats/**/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, f"profiles/{tag}_{HKD}_kernel_stats_batch16384_steps20.csv")
+    for n in ("steps20", "steps10"):
+        if os.path.exists(f"{out}/{HKD}_bench_{n}.json"):
+            shutil.copy(f"{out}/{HKD}_bench_{n}.json", f"profiles/{tag}_{HKD}_bench_batch16384_{n}.json")
+else:
+    st = find("stats/**/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, f"profiles/{tag}_kernel_stats_batch4096_steps20.csv")
+    for n in ("steps20", "steps10"):
+        if os.path.exists(f"{out}/bench_{n}.json"):
+            shutil.copy(f"{out}/bench_{n}.json", f"profiles/{tag}_bench_batch4096_{n}.json")
 
 
 def counter_by_kernel(d, counter):
@@ -45,9 +54,10 @@ def counter_by_kernel(d, counter):
     return acc, n
 
 
-fetch, nf = counter_by_kernel("pmc_fetch", "FETCH_SIZE")
-write, nw = counter_by_kernel("pmc_write", "WRITE_SIZE")
-bl = last_json_line(f"{out}/pmc_fetch_bench.json") or {}
+pre = f"{HKD}_" if HKD else ""
+fetch, nf = counter_by_kernel(pre + "pmc_fetch", "FETCH_SIZE")
+write, nw = counter_by_kernel(pre + "pmc_write", "WRITE_SIZE")
+bl = last_json_line(f"{out}/{pre}pmc_fetch_bench.json") or {}
 units = (bl.get("roofline") or {}).get("kernel_units_knots", {})
 # The rollout family = k_rollout_quad (whole-body running knots on lane quads) + k_rollout (terminal knots, single-rigid-body tail), ordinary
 # rollouts and the probe launches of the batched line search alike: bytes of both kernels over the knots (x candidates) both families processed
@@ -57,7 +67,8 @@ for acc in (fetch, write):
 for cnt in (nf, nw):
     if "k_rollout_quad" in cnt:
         cnt["k_rollout"] = cnt.get("k_rollout", 0) + cnt.pop("k_rollout_quad")
-units_by_kernel = {"k_rollout": units.get("k_rollout", 0) + units.get("k_ls_probe", 0), "k_lq": units.get("k_lq", 0), "k_sweep": units.get("k_sweep", 0), "k_sweep32": units.get("k_sweep", 0)}
+units_by_kernel = {"k_rollout": units.get("k_rollout", 0) + units.get("k_ls_probe", 0), "k_lq": units.get("k_lq", 0), "k_sweep": units.get("k_sweep", 0), "k_sweep32": units.get("k_sweep", 0),
+                   "k_rollout_hkd": units.get("k_rollout", 0) + units.get("k_ls_probe", 0), "k_lq_hkd": units.get("k_lq", 0), "k_sweep_hkd": units.get("k_sweep", 0)}
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (kernel-trace only); command: bench.py --steps 12 --warmup 0 "
                 "--batch 512 --no-cpu-baseline --no-latency.  Counters are in KB, summed over every launch of a kernel in the run and divided by the knots "
                 "(x line-search candidates) those launches processed (hsddp_get_kernel_units of the same run).  MI355X_MICROARCH.md: on gfx950 "
@@ -80,6 +91,10 @@ if "k_rollout" in traffic:
 if not res["kernels"]:
     sys.exit(f"no PMC data under {out}: nothing written")
 res["kernel_source_hash"] = SRC_HASH
+if HKD:
+    res["_note"] = res["_note"].replace("--batch 512", f"--hkd {HKD[3:]} --batch 2048").replace("--steps 12", "--steps 8")
+    json.dump(res, open(f"profiles/{tag}_{HKD}_pmc_batch2048.json", "w"), indent=1)
+    print("wrote profiles/%s_%s_*" % (tag, HKD), list(res["kernels"])); sys.exit(0)
 json.dump(res, open(f"profiles/{tag}_pmc_batch512.json", "w"), indent=1)
 # the file bench.py cites (roofline.traffic), valid only for the kernel sources it was measured on
 json.dump({"kernel_source_hash": SRC_HASH, "tag": tag, "kernels": traffic}, open("profiles/traffic.json", "w"), indent=1)
