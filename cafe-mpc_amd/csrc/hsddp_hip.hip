@@ -1222,6 +1222,13 @@ int hsddp_debug_lq_prof(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+#ifdef QUAD_PROF
+int hsddp_debug_quad_prof(unsigned long long* out24, int reset) {
+    hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_quad_prof), 24 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_quad_prof), z, sizeof(z)); }
+    return 0;
+}
+#endif
 #ifdef SW_PROF
 int hsddp_debug_sweep_prof(unsigned long long* out48, int reset) {
     hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_sw_prof), 48 * sizeof(unsigned long long));

@@ -57,6 +57,8 @@ struct QH {      // host: the four lanes of ONE quad together
     static S min(S a, S b) { return Q4(fmin(a.v[0], b.v[0]), fmin(a.v[1], b.v[1]), fmin(a.v[2], b.v[2]), fmin(a.v[3], b.v[3])); }
     static B gt(S a, S b) { return Q4b{{a.v[0] > b.v[0], a.v[1] > b.v[1], a.v[2] > b.v[2], a.v[3] > b.v[3]}}; }
     static S sel(B m, S a, S b) { return Q4(m.v[0] ? a.v[0] : b.v[0], m.v[1] ? a.v[1] : b.v[1], m.v[2] ? a.v[2] : b.v[2], m.v[3] ? a.v[3] : b.v[3]); }
+    static bool any(B m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+    static B lnot(B m) { return Q4b{{!m.v[0], !m.v[1], !m.v[2], !m.v[3]}}; }
     static bool any_bad(S x, double lim) { for (int l = 0; l < 4; l++) if (x.v[l] > lim || !(x.v[l] == x.v[l])) return true; return false; }
     static double lane0(S x) { return x.v[0]; }
 };
@@ -84,6 +86,8 @@ struct QD {      // GPU: S = one lane's double; the quad's other lanes are reach
     static HD S min(S a, S b) { return fmin(a, b); }
     static HD B gt(S a, S b) { return a > b; }
     static HD S sel(B m, S a, S b) { return m ? a : b; }
+    static HD bool any(B m) { return __any(m) != 0; }      // over the WAVE (uniform): only ever used to skip work no lane needs
+    static HD B lnot(B m) { return !m; }
     static HD double lane0(S x) { return x; }
 };
 #endif
@@ -190,11 +194,24 @@ template <class S> HD void base_walk(const Base3<S>& T, const V3<S>& fb, const V
 template <class Q, class S> HD S q_barrier(const S& g, const S& delta) {
     const typename Q::B above = Q::gt(g, delta);
     const S lg = Q::log(Q::sel(above, g, delta));
+    if (!Q::any(Q::lnot(above))) return -lg;      // no lane of the wave sits below its delta (the usual case): no division
     const S t = (g - 2.0 * delta) * Q::rcp(delta);
     return Q::sel(above, -lg, 0.5 * (t * t - 1.0) - lg);
 }
 
 struct QuadOut { double cost, dsq, ming; bool bad; };
+// diagnostic stamps (-DQUAD_PROF, tools/microbench.py): cycles of one wave from the middle of a launch between consecutive marks
+#if defined(QUAD_PROF) && !defined(HS_HOST_EMU)
+__device__ unsigned long long g_quad_prof[24];
+#define QP0() unsigned long long qp_t_ = 0; const bool qp_on_ = (blockIdx.x == HS_QUAD_PROF_BLOCK && threadIdx.x == 0); if (qp_on_) qp_t_ = clock64();
+#define QP(i) if (qp_on_) { const unsigned long long t_ = clock64(); atomicAdd(&g_quad_prof[i], t_ - qp_t_); qp_t_ = t_; }
+#ifndef HS_QUAD_PROF_BLOCK
+#define HS_QUAD_PROF_BLOCK 30011
+#endif
+#else
+#define QP0()
+#define QP(i)
+#endif
 template <int I> struct IC { static constexpr int value = I; };
 
 // One whole-body rollout knot k < h of problem b of a phase WITH shooting nodes, step length eps, evaluated by a lane quad.
@@ -207,6 +224,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     const bool WR = wr;
     const int h = P.h;
     const size_t kx = ((size_t)b * (h + 1) + k) * 36, ku = ((size_t)b * h + k) * 12, kk = (size_t)b * h + k;
+    QP0()
     // ---- state of the knot: the floating base replicated in every lane, the lane's own leg
     S qb[6], vb[6], ql[3], vl_[3], ul[3];
     _Pragma("unroll") for (int i = 0; i < 6; i++) { qb[i] = Q::ld(P.Xbar, kx + i, 0) + eps * Q::ld(P.dX, kx + i, 0); vb[i] = Q::ld(P.Xbar, kx + 18 + i, 0) + eps * Q::ld(P.dX, kx + 18 + i, 0); }
@@ -220,13 +238,72 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
             Q::st0(P.X, kx + j, qb[j]); Q::st0(P.X, kx + 3 + j, qb[3 + j]); Q::st0(P.X, kx + 18 + j, vb[j]); Q::st0(P.X, kx + 21 + j, vb[3 + j]);
         }
     }
+    // Everything of the knot that needs (x, u) only - the tracking cost, the torque / joint-speed / joint / height barriers - is evaluated HERE, its
+    // references and barrier parameters fetched with the state (one exposed round trip for all of them) and dead before the contact solve's
+    // register peak; what needs the dynamics (defect, foot costs, friction pyramid) reads later, ahead of the contact solve (see below).
+    const double dt = P.dt;
+    const HS_GLOBAL double* rr = P.rref + (size_t)k * 80;
+    const size_t gk = kk * P.ng;
+    const S zero = S(0.0);
+    const S w0 = Q::legc(1.0, 0.0, 0.0, 0.0);      // the replicated base entries are counted once
+    S lq, accT = zero, accS = zero, accJ = zero, accH = zero, gmin = zero;
+    {
+        S xrb[6], vrb[6], xrl[3], vrl[3], url[3];
+        S eT[6], dT[6], eS[6], dS[6], eJ[6], dJ[6], eH = zero, dH_ = S(1.0);
+        _Pragma("unroll") for (int i = 0; i < 6; i++) { xrb[i] = Q::ld(rr, i, 0); vrb[i] = Q::ld(rr, 18 + i, 0); }
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { xrl[j] = Q::ld(rr, 6 + j, 3); vrl[j] = Q::ld(rr, 24 + j, 3); url[j] = Q::ld(rr, 36 + j, 3); }
+        // entries 0..2: lower-bound half of the lane's three joints, 3..5: upper-bound half (12 constraints further).  One uniform branch per
+        // constraint object AROUND its twelve loads (a branch per load would put a wait between every pair)
+        _Pragma("unroll") for (int j = 0; j < 6; j++) { eT[j] = zero; dT[j] = S(1.0); eS[j] = zero; dS[j] = S(1.0); eJ[j] = zero; dJ[j] = S(1.0); }
+        if (P.go_torque >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eT[j] = Q::ld(P.eps, gk + P.go_torque + o, 3); dT[j] = Q::ld(P.delta, gk + P.go_torque + o, 3); } }
+        if (P.go_jspeed >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eS[j] = Q::ld(P.eps, gk + P.go_jspeed + o, 3); dS[j] = Q::ld(P.delta, gk + P.go_jspeed + o, 3); } }
+        if (P.go_joint >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eJ[j] = Q::ld(P.eps, gk + P.go_joint + o, 3); dJ[j] = Q::ld(P.delta, gk + P.go_joint + o, 3); } }
+        if (P.go_height >= 0) { eH = Q::ld(P.eps, gk + P.go_height, 0); dH_ = Q::ld(P.delta, gk + P.go_height, 0); }
+        QP(0)      // first reads issued
+        // running cost, tracking part (QuadraticTrackingCost): 0.5 (sum_x + sum_u) dt, formed like the wave kernel: l = 0.5 sx; l += 0.5 su; l *= dt
+        S sxq = zero, suq = zero;
+        _Pragma("unroll")
+        for (int i = 0; i < 6; i++) {
+            const S dq = qb[i] - xrb[i], dv = vb[i] - vrb[i];
+            sxq = sxq + w0 * (dq * P.q[i] * dq + dv * P.q[18 + i] * dv);
+        }
+        _Pragma("unroll")
+        for (int j = 0; j < 3; j++) {
+            const S dq = ql[j] - xrl[j], dv = vl_[j] - vrl[j], du = ul[j] - url[j];
+            // the phase's weights of the lane's leg: scalars of the descriptor picked by the lane (a per-lane index would be a vector load from constant memory)
+            const S wq = Q::legc(P.q[6 + j], P.q[9 + j], P.q[12 + j], P.q[15 + j]), wv = Q::legc(P.q[24 + j], P.q[27 + j], P.q[30 + j], P.q[33 + j]), wu = Q::legc(P.r[j], P.r[3 + j], P.r[6 + j], P.r[9 + j]);
+            sxq = sxq + (dq * wq * dq + dv * wv * dv);
+            suq = suq + du * wu * du;
+        }
+        sxq = Q::sum(sxq); suq = Q::sum(suq);
+        lq = 0.5 * sxq; lq = lq + 0.5 * suq; lq = lq * dt;
+        // path constraints on (x, u) of the lane's leg (MHPCConstraint.cpp:77-204): values, ReB cost per constraint object, minimum
+        auto six = [&](const S (&g)[6], const S (&e)[6], const S (&dl)[6], int c0, S& acc) {      // one constraint object: entries j / 12 + j of the lane's three joints
+            _Pragma("unroll") for (int j = 0; j < 6; j++) { acc = acc + e[j] * q_barrier<Q, S>(g[j], dl[j]); gmin = Q::min(gmin, g[j]); }
+            if (WR) { _Pragma("unroll") for (int j = 0; j < 6; j++) Q::st(P.g, gk + c0 + ((j < 3) ? j : 12 + j - 3), 3, g[j]); }
+            acc = Q::sum(acc);
+        };
+        if (P.go_torque >= 0) { const S g[6] = {-ul[0] + P.torque_limit, -ul[1] + P.torque_limit, -ul[2] + P.torque_limit, ul[0] + P.torque_limit, ul[1] + P.torque_limit, ul[2] + P.torque_limit}; six(g, eT, dT, P.go_torque, accT); }
+        if (P.go_jspeed >= 0) { const S g[6] = {vl_[0] - P.jspeed_lb, vl_[1] - P.jspeed_lb, vl_[2] - P.jspeed_lb, -vl_[0] + P.jspeed_ub, -vl_[1] + P.jspeed_ub, -vl_[2] + P.jspeed_ub}; six(g, eS, dS, P.go_jspeed, accS); }
+        if (P.go_joint >= 0) { const S g[6] = {ql[0] - P.joint_lb[0], ql[1] - P.joint_lb[1], ql[2] - P.joint_lb[2], -ql[0] + P.joint_ub[0], -ql[1] + P.joint_ub[1], -ql[2] + P.joint_ub[2]}; six(g, eJ, dJ, P.go_joint, accJ); }
+        if (P.go_height >= 0) {      // one constraint: evaluated by every lane on the same data, counted once
+            const S g = qb[2] - P.h_min;
+            if (WR) Q::st0(P.g, gk + P.go_height, g);
+            gmin = Q::min(gmin, g);
+            accH = eH * q_barrier<Q, S>(g, dH_);
+        }
+    }
     const S sx = Q::legc(1.0, 1.0, -1.0, -1.0), sy = Q::legc(1.0, -1.0, 1.0, -1.0);
     const double cps = md.cpsi_dyn, sps = md.spsi_dyn;      // every term of the rollout is a Pinocchio-equivalent one (quirk xii)
     Base3<S> T; S ca, sa, ch, sh, ck, sk;
-    Q::sincos(qb[3], T.s3, T.c3); Q::sincos(qb[4], T.s4, T.c4); Q::sincos(qb[5], T.s5, T.c5);
+    {   // the three base angles: lane l < 3 evaluates angle 3 + l (lane 3 repeats the last), the quad reads the results
+        const S ang = Q::legc(1, 0, 0, 0) * qb[3] + Q::legc(0, 1, 0, 0) * qb[4] + Q::legc(0, 0, 1, 1) * qb[5];
+        S sb, cb_; Q::sincos(ang, sb, cb_);
+        T.s3 = Q::template get<0>(sb); T.c3 = Q::template get<0>(cb_); T.s4 = Q::template get<1>(sb); T.c4 = Q::template get<1>(cb_); T.s5 = Q::template get<2>(sb); T.c5 = Q::template get<2>(cb_);
+    }
     Q::sincos(ql[0], sa, ca); Q::sincos(ql[1], sh, ch); Q::sincos(ql[2], sk, ck);
+    QP(1)      // trig
     const V3<S> pa = {sx * 0.19, sy * 0.049, S(0.0)}, ph = {S(0.0), sy * 0.062, S(0.0)}, pk = {S(0.0), S(0.0), S(-0.209)};
-    const S zero = S(0.0);
 
     // ---- composite inertias, leg -> trunk (frames: K shank, H thigh, A abad, B trunk; v_H = Ry(qk) v_K, v_A = Rz(psi) Ry(qh) v_H, v_B = Rx(qa) v_A)
     const RBI<S> IK = rbi_link<S>(0.064, zero, zero, S(-0.061), S(0.000245), zero, zero, S(0.000248), zero, S(0.000006));
@@ -240,6 +317,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     IT.m = Q::sum(IBl.m) + 3.3; IT.h = {Q::sum(IBl.h.x), Q::sum(IBl.h.y), Q::sum(IBl.h.z)};
     IT.I = {Q::sum(IBl.I.xx) + 0.011253, Q::sum(IBl.I.xy), Q::sum(IBl.I.xz), Q::sum(IBl.I.yy) + 0.036203, Q::sum(IBl.I.yz), Q::sum(IBl.I.zz) + 0.042673};
 
+    QP(2)      // composite inertias
     // ---- mass-matrix blocks of the leg: D (3x3, joints abad / hip / knee) and Ct[c][j] = M(base joint c, leg joint j)
     S Ct[6][3], d_aa, d_ha, d_hh, d_ka, d_kh, d_kk;
     {
@@ -270,6 +348,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         S t[6]; base_walk(T, f, n, t);
         _Pragma("unroll") for (int c = 0; c < 6; c++) Ct[c][0] = t[c];
     }
+    QP(3)      // D, Ct columns
     // ---- base block B (6x6, replicated): unit accelerations of the base joints seen in trunk axes, force of the WHOLE robot, walked back
     S Bm[21];
     {
@@ -288,6 +367,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
             _Pragma("unroll") for (int i = c; i < 6; i++) Bm[tri(i, c)] = t[i];
         }
     }
+    QP(4)      // base block
     // ---- bias forces: one Newton-Euler pass down and up the leg with the knot's velocities, zero acceleration, gravity as a base acceleration
     S hl[3], hb[6]; V3<S> fpos, fvel, jdv;
     V3<S> rB;      // foot relative to the trunk origin, trunk axes (for the Jacobian below)
@@ -359,6 +439,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         fb = {Q::sum(fb.x), Q::sum(fb.y), Q::sum(fb.z)}; nb = {Q::sum(nb.x), Q::sum(nb.y), Q::sum(nb.z)};
         base_walk(T, fb, nb, hb);
     }
+    QP(5)      // bias pass
     // ---- foot Jacobian of the leg, world axes: Ja (3 x 3 over abad, hip, knee), Jb (3 x 6 over the base joints) - geometric form axis x arm
     const S cl = Q::legc(P.contact[0] > 0 ? 1.0 : 0.0, P.contact[1] > 0 ? 1.0 : 0.0, P.contact[2] > 0 ? 1.0 : 0.0, P.contact[3] > 0 ? 1.0 : 0.0);      // contact flag of the lane's leg
     M33<S> Ja; S Jb[3][6];
@@ -376,6 +457,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         Jb[0][3] = j3.x; Jb[1][3] = j3.y; Jb[2][3] = j3.z; Jb[0][4] = j4.x; Jb[1][4] = j4.y; Jb[2][4] = j4.z; Jb[0][5] = j5.x; Jb[1][5] = j5.y; Jb[2][5] = j5.z;
     }
 
+    QP(6)      // Jacobian
     // Contact-solve cache of the knot (wr), in the layout of the one-wave programs (hs_types.hpp KC_*: factor in the legs-first order, X and the
     // Gram matrix over the compact contact columns), every piece stored as soon as it is final.  Column block of a foot = its rank among the
     // contact feet; the swing feet fill the padding blocks behind them.
@@ -396,6 +478,16 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         Q::st(kc, KC_FP, 3, fpos.x); Q::st(kc, KC_FP + 1, 3, fpos.y); Q::st(kc, KC_FP + 2, 3, fpos.z);
         Q::st(kc, KC_FV, 3, fvel.x); Q::st(kc, KC_FV + 1, 3, fvel.y); Q::st(kc, KC_FV + 2, 3, fvel.z);
     }
+    // ---- the reads of the tail (what needs the dynamics: next knot's state for the defect, foot-cost references, friction-pyramid parameters)
+    // are issued HERE: their round trip runs under the contact solve instead of being exposed at the end
+    S xnb[6], vnb[6], xnl[3], vnl[3];
+    auto read_next = [&]() {
+        _Pragma("unroll") for (int i = 0; i < 6; i++) { xnb[i] = Q::ld(P.Xbar, kx + 36 + i, 0) + eps * Q::ld(P.dX, kx + 36 + i, 0); vnb[i] = Q::ld(P.Xbar, kx + 54 + i, 0) + eps * Q::ld(P.dX, kx + 54 + i, 0); }
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { xnl[j] = Q::ld(P.Xbar, kx + 42 + j, 3) + eps * Q::ld(P.dX, kx + 42 + j, 3); vnl[j] = Q::ld(P.Xbar, kx + 60 + j, 3) + eps * Q::ld(P.dX, kx + 60 + j, 3); }
+    };
+#ifdef QUAD_NEXT_EARLY      // (measured: the 18 values held through the factorisation cost 24 spilled registers)
+    read_next();
+#endif
     // ---- contact solve, block form.  L = [ blockdiag(L_l) 0 ; E  L_S ],  E_l = Ct L_l^-T (6 x 3),  S = B - sum_l E_l E_l^T
     const Chol3<S> Ll = chol3<Q, S>(d_aa, d_ha, d_hh, d_ka, d_kh, d_kk);
     S E[6][3];
@@ -416,6 +508,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
             Q::st0(kc, KC_RDM + 12 + c, rdS[c]);
         }
     }
+    QP(7)      // chol3, E, Schur complement, chol6 (+ cache stores)
     // y = L^-1 (tau - h): leg part in the lane, base part replicated
     const V3<S> yl = fwd3(Ll, V3<S>{ul[0] - hl[0], ul[1] - hl[1], ul[2] - hl[2]});
     S yb[6];
@@ -440,6 +533,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         }
         _Pragma("unroll") for (int c = 0; c < 6; c++) _Pragma("unroll") for (int d = 0; d < 3; d++) Q::stv(kc, KC_X + (12 + c) * 12 + d, 3.0 * cb, all, Xb[c][d]);
     }
+    QP(8)      // y, X
     // Gram matrix G = X^T X in 3 x 3 blocks: lane f holds block row f (blocks g <= f), a swing leg's diagonal block is the identity
     // (its multiplier is zero); right-hand side  -X^T y - gam,  gam = Jdot v + 2 alpha J v (WBM.cpp:392-408)
     M33<S> G[4];
@@ -487,6 +581,7 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         const double a2 = 2.0 * P.bg_alpha;
         rhs = {cl * (-xy[0] - (jdv.x + a2 * fvel.x)), cl * (-xy[1] - (jdv.y + a2 * fvel.y)), cl * (-xy[2] - (jdv.z + a2 * fvel.z))};
     }
+    QP(9)      // Gram blocks, rhs
     // block Cholesky of G over the quad: block column kc is finished by lane kc (its diagonal block), then lanes f > kc form L_f,kc.
     // Lane f keeps its block row Lg[0..f]; blocks right of the diagonal are never used.
     M33<S> Lg[4]; Chol3<S> Ld;      // Lg[g]: block (own lane, g) of the factor, g < own lane ; Ld: the own diagonal block's factor
@@ -546,6 +641,21 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         V3<S> lam0 = bwd3(Ld, z - w30 - w20 - w10);                           // valid in lane 0
         rhs = {pick(lam0.x, lam1.x, lam2.x, lam3.x), pick(lam0.y, lam1.y, lam2.y, lam3.y), pick(lam0.z, lam1.z, lam2.z, lam3.z)};
     }
+    QP(10)     // block Cholesky + lam
+    // (second half of the tail's reads - foot-cost references, friction-pyramid parameters - behind the register peak of the factorisation)
+    S rel[3], fvr[3], rc, eG[5], dG[5];
+#ifndef QUAD_NEXT_EARLY
+    read_next();
+#endif
+    {
+        _Pragma("unroll") for (int j = 0; j < 3; j++) { rel[j] = Q::ld(rr, 64 + j, 3); fvr[j] = Q::ld(rr, 48 + j, 3); }
+        rc = Q::ld(rr, 60, 1);
+        _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = zero; dG[r] = S(1.0); }
+        if (P.go_grf >= 0) {      // per-lane constraint index go_grf + 5 slot + r: a swing lane reads a valid dummy (slot 0) and contributes nothing
+            const S ci0 = Q::sel(on, 5.0 * before, S(0.0));      // (one per-lane base, constant offsets r: the five loads share an address register)
+            _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = Q::ldv(P.eps, gk + P.go_grf + r, ci0); dG[r] = Q::ldv(P.delta, gk + P.go_grf + r, ci0); }
+        }
+    }
     const V3<S> lam = scale(cl, rhs);      // contact force of the lane's foot (world axes); zero for a swing leg
     // qdd = L^-T (y + X lam): base part replicated, leg part in the lane
     S qddb[6]; V3<S> qddl;
@@ -558,37 +668,8 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         qddl = bwd3(Ll, zl - V3<S>{et[0], et[1], et[2]});
     }
 
-    // ---- tail.  EVERY global read of the tail first, back to back and ahead of its stores (a store between two loads pins the later load behind
-    // it - the compiler cannot rule out aliasing - and a single wave per SIMD then pays one exposed round trip per load): the next knot's
-    // state, the knot's references, the barrier parameters of the lane's constraints.
-    const double dt = P.dt;
-    const HS_GLOBAL double* rr = P.rref + (size_t)k * 80;
-    const size_t gk = kk * P.ng;
-    S xnb[6], vnb[6], xnl[3], vnl[3], xrb[6], vrb[6], xrl[3], vrl[3], url[3], rel[3], fvr[3], rc;
-    S eT[6], dT[6], eS[6], dS[6], eJ[6], dJ[6], eH = zero, dH_ = S(1.0), eG[5], dG[5];
-    {
-        _Pragma("unroll") for (int i = 0; i < 6; i++) {
-            xnb[i] = Q::ld(P.Xbar, kx + 36 + i, 0) + eps * Q::ld(P.dX, kx + 36 + i, 0); vnb[i] = Q::ld(P.Xbar, kx + 54 + i, 0) + eps * Q::ld(P.dX, kx + 54 + i, 0);
-            xrb[i] = Q::ld(rr, i, 0); vrb[i] = Q::ld(rr, 18 + i, 0);
-        }
-        _Pragma("unroll") for (int j = 0; j < 3; j++) {
-            xnl[j] = Q::ld(P.Xbar, kx + 42 + j, 3) + eps * Q::ld(P.dX, kx + 42 + j, 3); vnl[j] = Q::ld(P.Xbar, kx + 60 + j, 3) + eps * Q::ld(P.dX, kx + 60 + j, 3);
-            xrl[j] = Q::ld(rr, 6 + j, 3); vrl[j] = Q::ld(rr, 24 + j, 3); url[j] = Q::ld(rr, 36 + j, 3); rel[j] = Q::ld(rr, 64 + j, 3); fvr[j] = Q::ld(rr, 48 + j, 3);
-        }
-        rc = Q::ld(rr, 60, 1);
-        // entries 0..2: lower-bound half of the lane's three joints, 3..5: upper-bound half (12 constraints further).  One uniform branch per
-        // constraint object AROUND its twelve loads (a branch per load would put a wait between every pair)
-        _Pragma("unroll") for (int j = 0; j < 6; j++) { eT[j] = zero; dT[j] = S(1.0); eS[j] = zero; dS[j] = S(1.0); eJ[j] = zero; dJ[j] = S(1.0); }
-        if (P.go_torque >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eT[j] = Q::ld(P.eps, gk + P.go_torque + o, 3); dT[j] = Q::ld(P.delta, gk + P.go_torque + o, 3); } }
-        if (P.go_jspeed >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eS[j] = Q::ld(P.eps, gk + P.go_jspeed + o, 3); dS[j] = Q::ld(P.delta, gk + P.go_jspeed + o, 3); } }
-        if (P.go_joint >= 0) { _Pragma("unroll") for (int j = 0; j < 6; j++) { const int o = (j < 3) ? j : 12 + j - 3; eJ[j] = Q::ld(P.eps, gk + P.go_joint + o, 3); dJ[j] = Q::ld(P.delta, gk + P.go_joint + o, 3); } }
-        if (P.go_height >= 0) { eH = Q::ld(P.eps, gk + P.go_height, 0); dH_ = Q::ld(P.delta, gk + P.go_height, 0); }
-        _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = zero; dG[r] = S(1.0); }
-        if (P.go_grf >= 0) {      // per-lane constraint index go_grf + 5 slot + r: a swing lane reads a valid dummy (slot 0) and contributes nothing
-            const S ci0 = Q::sel(on, 5.0 * before, S(0.0));      // (one per-lane base, constant offsets r: the five loads share an address register)
-            _Pragma("unroll") for (int r = 0; r < 5; r++) { eG[r] = Q::ldv(P.eps, gk + P.go_grf + r, ci0); dG[r] = Q::ldv(P.delta, gk + P.go_grf + r, ci0); }
-        }
-    }
+    QP(11)     // qdd
+    QP(12)     // (tail reads: issued ahead of the contact solve)
     if (WR) {
         _Pragma("unroll") for (int c = 0; c < 6; c++) Q::st0(kc, KC_QDD + c, qddb[c]);
         Q::st(kc, KC_QDD + 6, 3, qddl.x); Q::st(kc, KC_QDD + 7, 3, qddl.y); Q::st(kc, KC_QDD + 8, 3, qddl.z);
@@ -597,7 +678,6 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     }
     // ---- integrate (forward Euler, WBM.cpp:25-26), defect of knot k+1, divergence norm
     S dsq = zero, nsq = zero;
-    const S w0 = Q::legc(1.0, 0.0, 0.0, 0.0);      // the replicated base entries are counted once
     {
         _Pragma("unroll")
         for (int i = 0; i < 6; i++) {
@@ -633,28 +713,11 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         dsq = Q::sum(dsq); nsq = Q::sum(nsq);
     }
     if (WR) { Q::st(P.Y, kk * 12, 3, lam.x); Q::st(P.Y, kk * 12 + 1, 3, lam.y); Q::st(P.Y, kk * 12 + 2, 3, lam.z); }
-
-    // ---- running cost (QuadraticTrackingCost + the foot costs of MHPCCost.cpp:4-245), references of knot k from the phase's record
-    S lq;      // 0.5 (sum_x + sum_u) dt, formed like the wave kernel: l = 0.5 sx; l += 0.5 su; l *= dt
-    S lfoot2, lfoot3, lfoot4;
+    QP(13)     // integrate, defect
+    // ---- foot costs of the lane's foot (MHPCCost.cpp:4-245); the running cost in the reference's order of additions: tracking, foot-place
+    // regulariser, swing position, swing velocity, then dt x the ReB cost of each constraint object (SinglePhase.cpp:394-402)
+    S l = lq;
     {
-        S sxq = zero, suq = zero;
-        _Pragma("unroll")
-        for (int i = 0; i < 6; i++) {
-            const S dq = qb[i] - xrb[i], dv = vb[i] - vrb[i];
-            sxq = sxq + w0 * (dq * P.q[i] * dq + dv * P.q[18 + i] * dv);
-        }
-        _Pragma("unroll")
-        for (int j = 0; j < 3; j++) {
-            const S dq = ql[j] - xrl[j], dv = vl_[j] - vrl[j], du = ul[j] - url[j];
-            // the phase's weights of the lane's leg: scalars of the descriptor picked by the lane (a per-lane index would be a vector load from constant memory)
-            const S wq = Q::legc(P.q[6 + j], P.q[9 + j], P.q[12 + j], P.q[15 + j]), wv = Q::legc(P.q[24 + j], P.q[27 + j], P.q[30 + j], P.q[33 + j]), wu = Q::legc(P.r[j], P.r[3 + j], P.r[6 + j], P.r[9 + j]);
-            sxq = sxq + (dq * wq * dq + dv * wv * dv);
-            suq = suq + du * wu * du;
-        }
-        sxq = Q::sum(sxq); suq = Q::sum(suq);
-        lq = 0.5 * sxq; lq = lq + 0.5 * suq; lq = lq * dt;
-        // foot costs of the lane's foot
         const V3<S> d = {(fpos.x - qb[0]) - rel[0], (fpos.y - qb[1]) - rel[1], (fpos.z - qb[2]) - rel[2]};
         const V3<S> dv = {fvel.x - fvr[0], fvel.y - fvr[1], fvel.z - fvr[2]};
         const typename Q::B stance = Q::gt(rc, S(0.0)), swing = Q::gt(S(0.5), rc);      // (rc == 0 <=> swing: the flags are 0 / 1)
@@ -662,46 +725,33 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         const S wv0 = P.w_swing_vel[0], wv1 = P.w_swing_vel[1], wv2 = P.w_swing_vel[2];
         const S l2 = 0.5 * (d.x * wr0 * d.x + d.y * wr1 * d.y + d.z * wr2 * d.z) * dt, l3 = 0.5 * (d.x * wp0 * d.x + d.y * wp1 * d.y + d.z * wp2 * d.z) * dt;
         const S l4 = 0.5 * (dv.x * wv0 * dv.x + dv.y * wv1 * dv.y + dv.z * wv2 * dv.z) * dt;
-        lfoot2 = Q::sum(Q::sel(stance, (P.w_foot_reg[0] >= 0) ? l2 : zero, zero));
-        lfoot3 = Q::sum(Q::sel(swing, (P.w_swing_pos[0] >= 0) ? l3 : zero, zero));
-        lfoot4 = Q::sum(Q::sel(swing, (P.w_swing_vel[0] >= 0) ? l4 : zero, zero));
+        l = l + Q::sum(Q::sel(stance, (P.w_foot_reg[0] >= 0) ? l2 : zero, zero));
+        l = l + Q::sum(Q::sel(swing, (P.w_swing_pos[0] >= 0) ? l3 : zero, zero));
+        l = l + Q::sum(Q::sel(swing, (P.w_swing_vel[0] >= 0) ? l4 : zero, zero));
     }
-    S l = lq; l = l + lfoot2; l = l + lfoot3; l = l + lfoot4;
     if (WR) Q::st0(P.lbase, kk, l);
-
-    // ---- path constraints of the lane's leg (MHPCConstraint.cpp:9-204): values, ReB cost per constraint object, minimum
-    S gmin = zero;
-    {
-        auto six = [&](const S (&g)[6], const S (&e)[6], const S (&dl)[6], int c0) {      // one constraint object: entries j / 12 + j of the lane's three joints
-            S acc = zero;
-            _Pragma("unroll") for (int j = 0; j < 6; j++) { acc = acc + e[j] * q_barrier<Q, S>(g[j], dl[j]); gmin = Q::min(gmin, g[j]); }
-            if (WR) { _Pragma("unroll") for (int j = 0; j < 6; j++) Q::st(P.g, gk + c0 + ((j < 3) ? j : 12 + j - 3), 3, g[j]); }
-            if (reb_active) l = l + dt * Q::sum(acc);
-        };
-        if (P.go_torque >= 0) { const S g[6] = {-ul[0] + P.torque_limit, -ul[1] + P.torque_limit, -ul[2] + P.torque_limit, ul[0] + P.torque_limit, ul[1] + P.torque_limit, ul[2] + P.torque_limit}; six(g, eT, dT, P.go_torque); }
-        if (P.go_jspeed >= 0) { const S g[6] = {vl_[0] - P.jspeed_lb, vl_[1] - P.jspeed_lb, vl_[2] - P.jspeed_lb, -vl_[0] + P.jspeed_ub, -vl_[1] + P.jspeed_ub, -vl_[2] + P.jspeed_ub}; six(g, eS, dS, P.go_jspeed); }
-        if (P.go_joint >= 0) { const S g[6] = {ql[0] - P.joint_lb[0], ql[1] - P.joint_lb[1], ql[2] - P.joint_lb[2], -ql[0] + P.joint_ub[0], -ql[1] + P.joint_ub[1], -ql[2] + P.joint_ub[2]}; six(g, eJ, dJ, P.go_joint); }
-        if (P.go_height >= 0) {      // one constraint: evaluated by every lane on the same data, counted once
-            const S g = qb[2] - P.h_min;
-            if (WR) Q::st0(P.g, gk + P.go_height, g);
-            gmin = Q::min(gmin, g);
-            if (reb_active) l = l + dt * (eH * q_barrier<Q, S>(g, dH_));
+    QP(14)     // foot costs
+    if (reb_active) {
+        if (P.go_torque >= 0) l = l + dt * accT;
+        if (P.go_jspeed >= 0) l = l + dt * accS;
+        if (P.go_joint >= 0) l = l + dt * accJ;
+        if (P.go_height >= 0) l = l + dt * accH;
+    }
+    if (P.go_grf >= 0) {      // friction pyramid of the lane's foot (MHPCConstraint.cpp:9-70); its slot among the contact feet = number of contact feet before it
+        S acc = zero;
+        const double mu = P.mu;
+        const S gs[5] = {lam.z, -lam.x + mu * lam.z, lam.x + mu * lam.z, -lam.y + mu * lam.z, lam.y + mu * lam.z};
+        _Pragma("unroll")
+        for (int r = 0; r < 5; r++) {
+            const S g = Q::sel(on, gs[r], S(1.0));
+            if (WR) Q::stv(P.g, gk + P.go_grf, Q::sel(on, 5.0 * before + (double)r, S(0.0)), on, g);
+            acc = acc + Q::sel(on, eG[r] * q_barrier<Q, S>(g, dG[r]), zero);
+            gmin = Q::min(gmin, Q::sel(on, g, zero));
         }
-        if (P.go_grf >= 0) {      // friction pyramid of the lane's foot; its slot among the contact feet = number of contact feet before it
-            S acc = zero;
-            const double mu = P.mu;
-            const S gs[5] = {lam.z, -lam.x + mu * lam.z, lam.x + mu * lam.z, -lam.y + mu * lam.z, lam.y + mu * lam.z};
-            _Pragma("unroll")
-            for (int r = 0; r < 5; r++) {
-                const S g = Q::sel(on, gs[r], S(1.0));
-                if (WR) Q::stv(P.g, gk + P.go_grf, Q::sel(on, 5.0 * before + (double)r, S(0.0)), on, g);
-                acc = acc + Q::sel(on, eG[r] * q_barrier<Q, S>(g, dG[r]), zero);
-                gmin = Q::min(gmin, Q::sel(on, g, zero));
-            }
-            if (reb_active) l = l + dt * Q::sum(acc);
-        }
+        if (reb_active) l = l + dt * Q::sum(acc);
     }
     gmin = Q::vmin(gmin);
+    QP(15)     // constraints + barriers
     if (WR) Q::st0(P.l, kk, l);
     QuadOut o;
     o.cost = Q::lane0(l); o.dsq = Q::lane0(dsq); o.ming = Q::lane0(gmin);

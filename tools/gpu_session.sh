@@ -19,6 +19,9 @@ for step in "$@"; do
     swprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DSW_PROF" > $OUT/build_swprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/swprof.log 2>&1; echo "swprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/swprof.log ;;
     lqprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DLQ_PROF" > $OUT/build_lqprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/lqprof.log 2>&1; echo "lqprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/lqprof.log ;;
     quad2) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DQUAD_WPE=2" > $OUT/build_quad2.log 2>&1 && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/quad2_bench20.json 2> $OUT/quad2.err; echo "quad2 rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/quad2_bench20.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
+    quadprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DQUAD_PROF" > $OUT/build_quadprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/quadprof.log 2>&1; echo "quadprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/quadprof.log ;;
+    quadnext) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DQUAD_NEXT_EARLY" > $OUT/build_quadnext.log 2>&1 && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/quadnext_bench20.json 2> $OUT/quadnext.err; echo "quadnext rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/quadnext_bench20.json').read().strip().splitlines()[-1]); print('QUAD_NEXT_EARLY', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
+    benchq) timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/benchq.json').read().strip().splitlines()[-1]); print('default', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
     rebuild) make -C cafe-mpc_amd/csrc clean all > $OUT/build.log 2>&1; echo "rebuild rc=$?" | tee -a $OUT/summary.txt ;;
     *) echo "unknown step $step" ;;
   esac

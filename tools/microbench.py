@@ -39,6 +39,29 @@ if hasattr(lib, "hsddp_debug_sweep_prof"):
     tot = sum(buf[:16])
     for i, n in enumerate(names):
         print(f"  stamp {i} {n:26s} {buf[i] / 200:10.0f} cycles/knot ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
+if hasattr(lib, "hsddp_debug_quad_prof"):
+    buf = (ctypes.c_ulonglong * 24)()
+    names = ["first reads", "trig", "composite inertias", "D, Ct columns", "base block", "bias pass", "Jacobian", "chol3, E, Schur, chol6", "y, X", "Gram, rhs",
+             "block Cholesky, lam", "qdd", "tail reads", "integrate, defect", "running cost", "constraints, barriers"]
+    for label, eps_list in (("ordinary rollout (writes trajectories + cache)", None),):
+        lib.hsddp_debug_quad_prof(buf, 1)
+        s.hybrid_rollout(1.0, opt)
+        lib.hsddp_debug_quad_prof(buf, 0)
+        tot = sum(buf[:16])
+        print(f"  quad kernel, {label}: {tot} cycles for one wave (16 knots)")
+        for i, n in enumerate(names):
+            print(f"    quad stamp {i:2d} {n:28s} {buf[i]:8d} cycles ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
+    # a probe launch (nothing written): through a short fixed-work solve past convergence
+    s2 = pkg.MultiPhaseDDP(ph, batch=a.batch); s2.set_initial_condition(pkg.problems.wb_ensemble_x0(a.batch, 1))
+    o2 = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=9, cost_thresh=0.0)
+    s2.solve(o2)
+    lib.hsddp_debug_quad_prof(buf, 1)
+    o3 = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=1, cost_thresh=0.0); s2.solve(o3)
+    lib.hsddp_debug_quad_prof(buf, 0)
+    tot = sum(buf[:16]); kt2 = s2.kernel_times()
+    print(f"  quad kernel, one more iteration past convergence (initial rollout + full step + probe launch: stamps of the same block id summed over the launches): {tot} cycles; kernel times {kt2}")
+    for i, n in enumerate(names):
+        print(f"    quad stamp {i:2d} {n:28s} {buf[i]:8d} cycles ({100.0 * buf[i] / max(tot, 1):5.1f} %)")
 if hasattr(lib, "hsddp_debug_lq_prof") and os.environ.get("ROLL_PROF"):
     buf = (ctypes.c_ulonglong * 16)()
     lib.hsddp_debug_lq_prof(buf, 1)
