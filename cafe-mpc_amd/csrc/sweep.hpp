@@ -43,6 +43,9 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 #ifndef SW_MINB
 #define SW_MINB 2
 #endif
+#ifndef SW_OVERLAP_LDLT
+#define SW_OVERLAP_LDLT 1      // the factorisation of Quu (wave 0) side by side with the Qxx / Qux tiles (waves 1..3): see riccati_phase
+#endif
 
 // LDS working set of one Riccati step for a model with dims (N, M, PY); leading dimensions padded to rows + 1
 // (conflict-free column access).  All three instantiations are views over the same raw LDS block (SweepLds).
@@ -143,11 +146,15 @@ HD float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); ret
 // same sequence of multiply-adds as in Eigen's loops.  The multipliers go to LDS once, and lanes 0..M-1 each solve one column of
 // the identity.  Output: NI = -(A + diag_add I)^-1 (the sign the gains need), column-major with leading dimension LD.
 // Scratch: Lw >= M*M doubles, iw >= M ints.
-template <int M, int LD, class R>
-HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
+// PART: 0 = the whole routine as ONE wave-level phase of wave 0 (ldlt_inverse_w); 1 = pivot order + factorisation, 2 = the solves - called by the
+// lanes of wave 0 from inside two consecutive workgroup phases (SW_OVERLAP_LDLT: the other waves form the Qxx / Qux tiles and symmetrise Qxx
+// meanwhile); the factor (Lw) and the pivot order (iw) cross from part 1 to part 2 through LDS behind the workgroup barrier between them.
+template <int M, int LD, class R, int PART>
+HD void ldlt_parts(int tid, const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
     const R TOL = R(1.0) / std::numeric_limits<R>::max();
 #ifdef HS_HOST_EMU
-    HS_WPHASE(if (tid == 0) {      // the emulator has no lanes to broadcast between: Eigen's loops as they stand, with physical swaps
+    if (PART == 2) return;         // (the emulator's part 1 is the whole routine)
+    if (tid == 0) {      // the emulator has no lanes to broadcast between: Eigen's loops as they stand, with physical swaps
         R m[M * M]; int tr[M]; int sign = 0; (void)Lw; (void)iw;
         for (int j = 0; j < M; j++) for (int i = 0; i < M; i++) m[i + M * j] = A[i + LD * j] + (i == j ? diag_add : 0.0);
         auto Mx = [&](int i, int j) -> R& { return m[i + M * j]; };
@@ -179,7 +186,7 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
             for (int k = M - 1; k >= 0; k--) if (tr[k] != k) { const R t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
             for (int i = 0; i < M; i++) NI[i + LD * c] = -x[i];
         }
-    })
+    }
 #else
     static_assert(M <= 32, "one row per lane");
 #if defined(SW_PROF)
@@ -187,11 +194,12 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
 #else
 #define SW_LSTAMP(i)
 #endif
-    HS_WPHASE({
+    {
 #if defined(SW_PROF)
         unsigned long long tl_ = clock64();
 #endif
         const bool act = tid < M; const int me = act ? tid : M - 1;       // idle lanes mirror the last row (all 64 lanes run the broadcasts)
+        if (PART != 2) {
         // ---- pivot order
         R dg[M];
         _Pragma("unroll") for (int j = 0; j < M; j++) dg[j] = fabs(A[j + LD * j] + diag_add);
@@ -216,8 +224,10 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         SW_LSTAMP(9)
+        }
         int pv[M]; int myrank = 0;
         _Pragma("unroll") for (int k = 0; k < M; k++) { pv[k] = iw[k]; myrank = (pv[k] == me) ? k : myrank; }
+        if (PART != 2) {
         const int prow = iw[me];
         // ---- row `me` of the permuted matrix (lower triangle of the input only)
         R arow[M];
@@ -243,6 +253,8 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
         }
         SW_LSTAMP(11)
         if (tid == 0 && anyneg) *ok = 0;       // isPositive(): no negative pivot (Eigen's sign bookkeeping ends in PositiveSemiDef / ZeroSign exactly then)
+        }
+        if (PART == 1) return;
         // ---- column `me` of the inverse: P e_me is the unit vector at position myrank.  The factor row of the next step is fetched
         //      (broadcast reads) while the current row's multiply-add chain runs: a single wave has nothing else to hide the LDS latency behind.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -271,8 +283,12 @@ HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
         }
         if (act) { _Pragma("unroll") for (int k = 0; k < M; k++) NI[pv[k] + LD * me] = -y[k]; }
         SW_LSTAMP(13)
-    })
+    }
 #endif
+}
+template <int M, int LD, class R>
+HD void ldlt_inverse_w(const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
+    HS_WPHASE(ldlt_parts<M, LD, R, 0>(tid, A, diag_add, NI, Lw, iw, ok);)
 }
 // global (dense, ld = rows) <-> LDS (padded ld); threads stride over columns with a fixed row
 template <int NT, class TD, class TS> HD void ld_mat(int tid, TD* dst, int ldd, const TS* src, int rows, int cols) {
@@ -337,18 +353,20 @@ HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane, R dt) {
     }
     mfma_tiles<(NTL > 0 ? NTL : 1), ((AR > PY ? AR : PY) + 3) / 4 * 4, 0, R>(lane, td);
 }
-template <int W, int N, int M, int PY, class R>
+// DEAL 0: every tile round-robin over the four waves.  DEAL 1 (SW_OVERLAP_LDLT): the Quu tiles on wave 0 - which goes straight on to the factorisation of
+// Quu while waves 1..3 share the Qxx and Qux tiles (the factorisation needs nothing else of this phase)
+template <int W, int N, int M, int PY, class R, int DEAL = 0>
 HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
     constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM, AR = SweepLdsT<N, M, PY, R>::AR, LDA = SweepLdsT<N, M, PY, R>::LDA, A0 = SweepLdsT<N, M, PY, R>::A0;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16;
     // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
     // body), the symmetrisation step of the reference (SinglePhase.cpp:376) fills the rest
     constexpr int t1 = TN * (TN + 1) / 2, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
-    constexpr int NTL = (t3 - W + 3) / 4;
+    constexpr int NTL = DEAL == 0 ? (t3 - W + 3) / 4 : (W == 0 ? t3 - t2 : (t2 - (W - 1) + 2) / 3);
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int t = W + 4 * q;
+        const int t = DEAL == 0 ? W + 4 * q : (W == 0 ? t2 + q : (W - 1) + 3 * q);
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
         // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
@@ -430,6 +448,49 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
             SW_WSTAMP(0)
         })
         SW_STAMP(1)
+#if SW_OVERLAP_LDLT
+        // phase 2, two jobs side by side.  Wave 0: the Quu tiles (Quu += B^T HB + D^T lD, regularisation on the diagonal) and straight on - no workgroup
+        // barrier, its own tile - to Eigen's pivoted LDLT of (Quu - 1e-9 I): pivot order + factorisation (SinglePhase.cpp:366-372).  Waves 1..3: Qxx - lxx =
+        // A^T HA + C^T lC (into the H block), Qux = B^T HA + D^T lC, and the chains Qx += A^T Gn + C^T ly, Qu += B^T Gn + D^T ly.  The factorisation
+        // needs nothing else of this phase, so its 5.5 k cycles run under the other waves' tiles instead of behind them.
+        // Scratch of the LDLT: the HB block (only the Quu tiles read it, and they are wave 0's own).
+        HS_PHASE_L(NT, {
+            const int w = tid >> 6, lane = tid & 63;
+            switch (w) { case 0: sweep_tiles2<0, N, M, PY, R, 1>(S, lane, reg, dtR); break; case 1: sweep_tiles2<1, N, M, PY, R, 1>(S, lane, reg, dtR); break;
+                         case 2: sweep_tiles2<2, N, M, PY, R, 1>(S, lane, reg, dtR); break; default: sweep_tiles2<3, N, M, PY, R, 1>(S, lane, reg, dtR); }
+            if (tid >= 128 && tid < 128 + N) {
+                const int i = tid - 128; R s = 0;
+                if (A0 > 0) s = (i < A0) ? S.Gn[i] : dtR * S.Gn[i - A0];       // [I, dt I]^T Gn(:A0): the upper rows of the whole-body A
+                _Pragma("unroll 6") for (int t = 0; t < AR; t++) s += CM(S.A, t, i, LDA) * S.Gn[A0 + t];
+                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.C, t, i, LDM) * S.ly[t]; }
+                S.Qx[i] += s;
+            } else if (tid >= 192 && tid < 192 + M) {
+                const int a = tid - 192; R s = 0;
+                _Pragma("unroll 6") for (int t = 0; t < AR; t++) s += CM(S.B, t, a, LDA) * S.Gn[A0 + t];
+                if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
+                S.Qu[a] += s;
+            }
+            if (w == 0) {
+#ifndef HS_HOST_EMU
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the wave's own Quu tile
+#endif
+                ldlt_parts<M, LDM, R, 1>(lane, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok);
+            }
+            SW_WSTAMP(1)
+        })
+        SW_STAMP(2)
+        // wave 0: the solves, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:375) ; waves 1..3: symmetrise Qxx (SinglePhase.cpp:376)
+        HS_PHASE_L(NT,
+            if (tid < 64) ldlt_parts<M, LDM, R, 2>(tid, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok);
+            else for (int e = tid - 64; e < N * N; e += NT - 64) {
+                const int i = e % N, j = e / N;
+                if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
+                    const R s = (i / 16 == j / 16) ? (CM(S.H, i, j, LDN) + CM(S.H, j, i, LDN)) / 2 : CM(S.H, i, j, LDN);
+                    CM(S.H, i, j, LDN) = s; CM(S.H, j, i, LDN) = s;
+                }
+            })
+        SW_STAMP(5)
+#else
         // phase 2: Qxx - lxx = A^T HA + C^T lC (TN x TN, into the H block) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
@@ -469,6 +530,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                 }
             })
         SW_STAMP(5)
+#endif
         if (!SWC.ok) return false;
         SW_STAMP(6)
         // K = -Quu_inv Qux on the matrix cores (TM x TN tiles over the waves) ; dU = -Quu_inv Qu on the last lanes   (SinglePhase.cpp:379-380)
@@ -490,7 +552,14 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
             else if (tid == DV0) { R dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
             else if (tid >= DU0 && tid < DU0 + M) { const int a = tid - DU0; gdU[kk * M + a] = S.dU[a]; } SW_WSTAMP(3))
         SW_STAMP(7)
+#if SW_OVERLAP_LDLT
+        // stores: the gains, and Qu / Quu / Qux as the reference keeps them (Quu carries the regularisation, SinglePhase.cpp:364-365) - by every wave alike,
+        // so that the count of stores between the record prefetch and its commit is the same on all of them
+        HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N); if (tid < M) gQu[kk * M + tid] = S.Qu[tid];
+                   st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
+#else
         HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N);)
+#endif
         SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
