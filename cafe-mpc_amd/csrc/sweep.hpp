@@ -331,19 +331,23 @@ template <> HD const HS_GLOBAL float* rec_of<float>(const PhaseDev& P) { return 
 
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
-template <int W, int N, int M, int PY, class R>
+// DEAL 1 (SW_OVERLAP_LDLT): wave 0 forms what only Quu needs - the HB and lD tiles - and goes on to the Quu tiles inside the same phase; waves 1..3 share
+// the HA and lC tiles
+template <int W, int N, int M, int PY, class R, int DEAL = 0>
 HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane, R dt) {
     constexpr int LDN = SweepLdsT<N, M, PY, R>::LDN, LDM = SweepLdsT<N, M, PY, R>::LDM, AR = SweepLdsT<N, M, PY, R>::AR, LDA = SweepLdsT<N, M, PY, R>::LDA, A0 = SweepLdsT<N, M, PY, R>::A0;
     constexpr int TN = (N + 15) / 16, TM = (M + 15) / 16, TP = (PY + 15) / 16, TPd = TP > 0 ? TP : 1;
     constexpr int t1 = TN * TN, t2 = t1 + TN * TM, t3 = t2 + TP * TN, t4 = t3 + TP * TM;
     // tiles dealt round-robin, t = W + 4 q - except for the whole-body sizes (16 tiles), where the per-wave stamps (tools/microbench.py, -DSW_PROF)
     // put wave 3 (HA, HA, HB(32,0), lD) 1.3 k cycles behind wave 0 (HA, HA, HA, lC): the lD tile goes to wave 0
-    constexpr bool WBT = (t4 == 16 && t3 == 15);
-    constexpr int NTL = WBT ? (W == 0 ? 5 : W == 3 ? 3 : 4) : (t4 - W + 3) / 4;
+    constexpr bool WBT = (DEAL == 0 && t4 == 16 && t3 == 15);
+    constexpr int nA = t1 + (t3 - t2), nB = (t2 - t1) + (t4 - t3);      // DEAL 1: tiles of waves 1..3 (HA, lC) / of wave 0 (HB, lD)
+    constexpr int NTL = DEAL == 1 ? (W == 0 ? nB : (nA - (W - 1) + 2) / 3) : WBT ? (W == 0 ? 5 : W == 3 ? 3 : 4) : (t4 - W + 3) / 4;
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int t = (WBT && W == 0 && q == 4) ? 15 : W + 4 * q;
+        const int ix = (W - 1) + 3 * q;
+        const int t = DEAL == 1 ? (W == 0 ? (q < t2 - t1 ? t1 + q : t3 + (q - (t2 - t1))) : (ix < t1 ? ix : t2 + (ix - t1))) : (WBT && W == 0 && q == 4) ? 15 : W + 4 * q;
         // HA = H A = H(:, A0:) A_low (+ H [I, dt I] when the upper rows of A are the forward-Euler identities) ; HB = H(:, A0:) B_low
         if (t < t1) { td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H + LDN * A0, LDN, S.A, LDA, AR, false, nullptr, 0, nullptr, 0, 0};
                       if (A0 > 0) { td[q].T = S.H; td[q].ldt = LDN; td[q].tmode = 1; td[q].tsplit = A0; td[q].tscale = dt; } }
@@ -440,8 +444,20 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
         // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
+#if SW_OVERLAP_LDLT
+            // wave 0: HB, lD - what only Quu needs - and, without a workgroup barrier (its own tiles), the Quu tiles themselves: Quu += B^T HB + D^T lD with the
+            // regularisation on the diagonal; waves 1..3: HA, lC
+            switch (w) { case 0: sweep_tiles1<0, N, M, PY, R, 1>(S, lane, dtR);
+#ifndef HS_HOST_EMU
+                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+                                 sweep_tiles2<0, N, M, PY, R, 1>(S, lane, reg, dtR); break;
+                         case 1: sweep_tiles1<1, N, M, PY, R, 1>(S, lane, dtR); break;
+                         case 2: sweep_tiles1<2, N, M, PY, R, 1>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R, 1>(S, lane, dtR); }
+#else
             switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane, dtR); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane, dtR); break;
                          case 2: sweep_tiles1<2, N, M, PY, R>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane, dtR); }
+#endif
             // (whole body: the Gnext chain rides on wave 1 - per-wave stamps show it 2.5 k cycles ahead of wave 0, which carries three of the nine HA
             // tiles; the 24 / 12-row models deal two tiles to every wave and keep it on wave 0)
             if (tid >= GN0 && tid < GN0 + N) { const int i = tid - GN0; R s = S.G[i]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; }
@@ -449,14 +465,14 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
         })
         SW_STAMP(1)
 #if SW_OVERLAP_LDLT
-        // phase 2, two jobs side by side.  Wave 0: the Quu tiles (Quu += B^T HB + D^T lD, regularisation on the diagonal) and straight on - no workgroup
-        // barrier, its own tile - to Eigen's pivoted LDLT of (Quu - 1e-9 I): pivot order + factorisation (SinglePhase.cpp:366-372).  Waves 1..3: Qxx - lxx =
+        // phase 2, two jobs side by side.  Wave 0 (its Quu tiles are done: phase 1): Eigen's pivoted LDLT of (Quu - 1e-9 I), pivot order + factorisation
+        // (SinglePhase.cpp:366-372).  Waves 1..3: Qxx - lxx =
         // A^T HA + C^T lC (into the H block), Qux = B^T HA + D^T lC, and the chains Qx += A^T Gn + C^T ly, Qu += B^T Gn + D^T ly.  The factorisation
         // needs nothing else of this phase, so its 5.5 k cycles run under the other waves' tiles instead of behind them.
         // Scratch of the LDLT: the HB block (only the Quu tiles read it, and they are wave 0's own).
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-            switch (w) { case 0: sweep_tiles2<0, N, M, PY, R, 1>(S, lane, reg, dtR); break; case 1: sweep_tiles2<1, N, M, PY, R, 1>(S, lane, reg, dtR); break;
+            switch (w) { case 0: break; case 1: sweep_tiles2<1, N, M, PY, R, 1>(S, lane, reg, dtR); break;
                          case 2: sweep_tiles2<2, N, M, PY, R, 1>(S, lane, reg, dtR); break; default: sweep_tiles2<3, N, M, PY, R, 1>(S, lane, reg, dtR); }
             if (tid >= 128 && tid < 128 + N) {
                 const int i = tid - 128; R s = 0;
@@ -470,12 +486,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                 if (PY > 0) { _Pragma("unroll 6") for (int t = 0; t < PY; t++) s += CM(S.D, t, a, LDM) * S.ly[t]; }
                 S.Qu[a] += s;
             }
-            if (w == 0) {
-#ifndef HS_HOST_EMU
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // the wave's own Quu tile
-#endif
-                ldlt_parts<M, LDM, R, 1>(lane, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok);
-            }
+            if (w == 0) ldlt_parts<M, LDM, R, 1>(lane, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok);
             SW_WSTAMP(1)
         })
         SW_STAMP(2)
