@@ -467,13 +467,13 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
     const S before = Q::legc(0, 1, 0, 0) * cf0 + Q::legc(0, 0, 1, 0) * (cf0 + cf1) + Q::legc(0, 0, 0, 1) * (cf0 + cf1 + cf2);      // contact feet in front of the lane's
     const typename Q::B on = Q::gt(cl, S(0.5)), all = Q::gt(S(1.0), S(0.0));
     const S cb = Q::sel(on, before, (cf0 + cf1 + cf2 + cf3) + (lane - before));
-    if (WR) {      // all-feet Jacobian (12 x 18, joint-order columns): the foot's rows - base columns, its own leg's columns, zeros for the other legs
+    // (Structural zeros of the cache image - the other legs' columns of a foot's Jacobian rows, the other feet's columns of a leg's rows of X - are
+    // never stored: the buffer is zero-filled when it is laid out, hsddp_create / hsddp_reconfigure, the contact pattern of a phase never changes,
+    // and the one-wave program writes exact zeros there.)
+    if (WR) {      // all-feet Jacobian (12 x 18, joint-order columns): the foot's rows - base columns and its own leg's columns
         _Pragma("unroll") for (int r = 0; r < 3; r++) {
             _Pragma("unroll") for (int c = 0; c < 6; c++) Q::st(kc, KC_J + 18 * r + c, 54, Jb[r][c]);
-            _Pragma("unroll") for (int g = 0; g < 4; g++) {
-                const S m = Q::legc(g == 0, g == 1, g == 2, g == 3);
-                Q::st(kc, KC_J + 18 * r + 6 + 3 * g, 54, m * Ja.r[r].x); Q::st(kc, KC_J + 18 * r + 7 + 3 * g, 54, m * Ja.r[r].y); Q::st(kc, KC_J + 18 * r + 8 + 3 * g, 54, m * Ja.r[r].z);
-            }
+            Q::st(kc, KC_J + 18 * r + 6, 57, Ja.r[r].x); Q::st(kc, KC_J + 18 * r + 7, 57, Ja.r[r].y); Q::st(kc, KC_J + 18 * r + 8, 57, Ja.r[r].z);
         }
         Q::st(kc, KC_FP, 3, fpos.x); Q::st(kc, KC_FP + 1, 3, fpos.y); Q::st(kc, KC_FP + 2, 3, fpos.z);
         Q::st(kc, KC_FV, 3, fvel.x); Q::st(kc, KC_FV + 1, 3, fvel.y); Q::st(kc, KC_FV + 2, 3, fvel.z);
@@ -526,10 +526,9 @@ HD QuadOut wbq_rollout_knot(PhaseC& P, const ModelDev& md, int b, int k, double 
         _Pragma("unroll") for (int c = 0; c < 6; c++) Xb[c][d] = w[c];
     }
     if (WR) {      // X = L^-1 Jc^T (18 x 12, row-major over the legs-first rows): the leg's rows hold its own block only, the base rows one column block per lane
-        _Pragma("unroll") for (int j = 0; j < 3; j++) _Pragma("unroll") for (int a = 0; a < 12; a++) {
-            const S xv = (a % 3 == 0) ? (j == 0 ? Xt.r[0].x : j == 1 ? Xt.r[0].y : Xt.r[0].z) : (a % 3 == 1) ? (j == 0 ? Xt.r[1].x : j == 1 ? Xt.r[1].y : Xt.r[1].z) : (j == 0 ? Xt.r[2].x : j == 1 ? Xt.r[2].y : Xt.r[2].z);
-            const typename Q::B mine = Q::gt(S(0.25), (cb - (double)(a / 3)) * (cb - (double)(a / 3)));
-            Q::st(kc, KC_X + 12 * j + a, 36, Q::sel(mine, xv, zero));
+        _Pragma("unroll") for (int d = 0; d < 3; d++) {      // rows 3 lane + j, columns 3 cb + d: the lane's own 3 x 3 block (a swing lane's block is zero)
+            const S ix = 36.0 * lane + 3.0 * cb + (double)d;
+            Q::stv(kc, KC_X, ix, on, Xt.r[d].x); Q::stv(kc, KC_X + 12, ix, on, Xt.r[d].y); Q::stv(kc, KC_X + 24, ix, on, Xt.r[d].z);
         }
         _Pragma("unroll") for (int c = 0; c < 6; c++) _Pragma("unroll") for (int d = 0; d < 3; d++) Q::stv(kc, KC_X + (12 + c) * 12 + d, 3.0 * cb, all, Xb[c][d]);
     }

@@ -22,6 +22,8 @@ for step in "$@"; do
     quadprof) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DQUAD_PROF" > $OUT/build_quadprof.log 2>&1 && timeout -k 10 300 python3 tools/microbench.py > $OUT/quadprof.log 2>&1; echo "quadprof rc=$?" | tee -a $OUT/summary.txt; cat $OUT/quadprof.log ;;
     quadnext) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -DQUAD_NEXT_EARLY" > $OUT/build_quadnext.log 2>&1 && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/quadnext_bench20.json 2> $OUT/quadnext.err; echo "quadnext rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/quadnext_bench20.json').read().strip().splitlines()[-1]); print('QUAD_NEXT_EARLY', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
     benchq) timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/benchq.json').read().strip().splitlines()[-1]); print('default', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
+    maxilp) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -mllvm -amdgpu-sched-strategy=max-ilp" > $OUT/build_maxilp.log 2>&1 && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/maxilp_bench20.json 2> $OUT/maxilp.err; echo "maxilp rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/maxilp_bench20.json').read().strip().splitlines()[-1]); print('max-ilp', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
+    maxocc) make -C cafe-mpc_amd/csrc clean all EXTRA="-DROLL_WPE=2 -mllvm -amdgpu-sched-strategy=max-memory-clause" > $OUT/build_maxocc.log 2>&1 && timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-latency > $OUT/maxocc_bench20.json 2> $OUT/maxocc.err; echo "maxocc rc=$?" | tee -a $OUT/summary.txt; python3 -c "import json,sys; d=json.loads(open('$OUT/maxocc_bench20.json').read().strip().splitlines()[-1]); print('max-memory-clause', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])" ;;
     rebuild) make -C cafe-mpc_amd/csrc clean all > $OUT/build.log 2>&1; echo "rebuild rc=$?" | tee -a $OUT/summary.txt ;;
     *) echo "unknown step $step" ;;
   esac
