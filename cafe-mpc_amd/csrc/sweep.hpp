@@ -43,6 +43,9 @@ constexpr int SW_PRE = 20;  // prefetch registers per thread
 #ifndef SW_MINB
 #define SW_MINB 2
 #endif
+#ifndef SW_LDLT_WDW
+#define SW_LDLT_WDW 1          // the explicit inverse as W^T D^-1 W on the matrix cores (W = L^-1 P) instead of the backward solves
+#endif
 #ifndef SW_OVERLAP_LDLT
 #define SW_OVERLAP_LDLT 1      // the factorisation of Quu (wave 0) side by side with the Qxx / Qux tiles (waves 1..3): see riccati_phase
 #endif
@@ -149,8 +152,9 @@ HD float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); ret
 // PART: 0 = the whole routine as ONE wave-level phase of wave 0 (ldlt_inverse_w); 1 = pivot order + factorisation, 2 = the solves - called by the
 // lanes of wave 0 from inside two consecutive workgroup phases (SW_OVERLAP_LDLT: the other waves form the Qxx / Qux tiles and symmetrise Qxx
 // meanwhile); the factor (Lw) and the pivot order (iw) cross from part 1 to part 2 through LDS behind the workgroup barrier between them.
+// W1 / W2 (PART 2 with SW_LDLT_WDW, >= M*M each): where the columns of W = L^-1 P and of -D^-1 W are laid for the matrix-core product NI = W^T (-D^-1 W)
 template <int M, int LD, class R, int PART>
-HD void ldlt_parts(int tid, const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok) {
+HD void ldlt_parts(int tid, const R* A, R diag_add, R* NI, R* Lw, int* iw, int* ok, R* W1 = nullptr, R* W2 = nullptr) {
     const R TOL = R(1.0) / std::numeric_limits<R>::max();
 #ifdef HS_HOST_EMU
     if (PART == 2) return;         // (the emulator's part 1 is the whole routine)
@@ -271,6 +275,21 @@ HD void ldlt_parts(int tid, const R* A, R diag_add, R* NI, R* Lw, int* iw, int* 
             y[k] = sacc;
         }
         SW_LSTAMP(12)
+#if SW_LDLT_WDW
+        if (PART == 2 && sizeof(R) == 8) {      // (fp64 only: in fp32 the product form loses a digit against the substitutions - measured on the kinodynamic trot: |dU| error 5e-3 against 5e-4)
+            // Quu^-1 = P^T L^-T D^-1 L^-1 P = W^T D^-1 W with W = L^-1 P, whose column `me` this lane has just formed: instead of M^2/2 more dependent
+            // multiply-adds per lane (the backward solves) the columns go to LDS once and ONE matrix-core product per 16 x 16 tile forms the (negated)
+            // inverse.  Same factors and pivots as LDLT.solve(I) (SinglePhase.cpp:375); the sums run over k in the matrix cores' order.
+            if (act) { _Pragma("unroll") for (int k = 0; k < M; k++) { W1[k + M * me] = y[k]; W2[k + M * me] = -(y[k] * Lw[k * M + k]); } }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int TMq = (M + 15) / 16;
+            MTileT<R> td[TMq * TMq];
+            _Pragma("unroll") for (int t = 0; t < TMq * TMq; t++) td[t] = MTileT<R>{NI, LD, nullptr, 0, 16 * (t % TMq), 16 * (t / TMq), M, M, W1, M, W2, M, M, true, nullptr, 0, nullptr, 0, 0};
+            mfma_tiles<TMq * TMq, (M + 3) / 4 * 4, 0, R>(tid, td);
+            SW_LSTAMP(13)
+            return;
+        }
+#endif
         _Pragma("unroll") for (int k = 0; k < M; k++) y[k] = y[k] * Lw[k * M + k];
         _Pragma("unroll") for (int k = M - 1; k >= 0; k--) {
             if (NB == 2) { if (k > 0) { _Pragma("unroll") for (int j = k; j < M; j++) lr[(k - 1) % NB][j] = Lw[j * M + (k - 1)]; } }
@@ -492,7 +511,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
         SW_STAMP(2)
         // wave 0: the solves, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:375) ; waves 1..3: symmetrise Qxx (SinglePhase.cpp:376)
         HS_PHASE_L(NT,
-            if (tid < 64) ldlt_parts<M, LDM, R, 2>(tid, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok);
+            if (tid < 64) ldlt_parts<M, LDM, R, 2>(tid, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok, S.HA, S.A);      // (HA, A: dead since phase 2)
             else for (int e = tid - 64; e < N * N; e += NT - 64) {
                 const int i = e % N, j = e / N;
                 if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
