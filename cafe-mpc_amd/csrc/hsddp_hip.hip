@@ -23,6 +23,8 @@
 
 using namespace hs;
 
+// the host's control flow reads four counters the stream delivers: synchronise, check the launches before it, and refuse counters that never arrived
+#define SYNC_COUNTERS() do { HIPCK(hipStreamSynchronize(h->stream)); HIPCK(hipGetLastError()); if (h->h_counters[0] < 0 || h->h_counters[1] < 0 || h->h_counters[2] < 0 || h->h_counters[3] < 0) { fprintf(stderr, "[hsddp_hip] counters not delivered (%s:%d)\n", __FILE__, __LINE__); return HSDDP_ENODEV; } } while (0)
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[hsddp_hip] %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return HSDDP_ENODEV; } } while (0)
 
 struct SlotArrays { double *cost, *dsq, *ming, *maxh; };
@@ -152,6 +154,9 @@ __global__ void __launch_bounds__(64) ROLL_HKD_ATTR k_rollout_hkd(ROLL_ARGS) { _
 
 // The whole-body running knots of the phases with shooting nodes on LANE QUADS (wb_quad.hpp): one lane per leg, sixteen problems of the same
 // (candidate, knot) per wave.  grid = candidates x knots of the list x ceil(batch / 16); qslots: the slots this kernel owns.
+#ifndef QUAD_CAND_MAJOR
+#define QUAD_CAND_MAJOR 0      // 1: the round-3a order (candidate slowest)
+#endif
 #ifndef QUAD_WPE
 #define QUAD_WPE 1      // waves per SIMD the quad kernel is compiled for (1: up to 512 registers, nothing in scratch; 2: 256 registers)
 #endif
@@ -161,7 +166,20 @@ k_rollout_quad(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, co
     PhaseC* ph = (PhaseC*)ph_;
     const int nbg = (batch + 15) >> 4;
     const int per = nq * nbg;
-    const int c = blockIdx.x / per, r = blockIdx.x - c * per;
+    // Workgroups go round-robin over the 8 XCDs (one L2 each).  The candidates of a unit (16 problems x one knot) read the same trajectories
+    // and differ in eps only: unit u lives on XCD u % 8 and its candidates occupy consecutive dispatch slots of that XCD, so one of them brings
+    // the lines into that L2 and the others find them there (candidate-major order streamed the whole ensemble from HBM once per candidate).
+    const int ncand = gridDim.x / per;
+    int c, r;
+#if QUAD_CAND_MAJOR
+    c = blockIdx.x / per; r = blockIdx.x - c * per;
+#else
+    {
+        const int full = (per >> 3) << 3, g = blockIdx.x;
+        if (g < full * ncand) { const int G = g / (8 * ncand), rem = g - G * 8 * ncand; c = rem >> 3; r = G * 8 + (rem & 7); }
+        else { const int nt = per - full, g2 = g - full * ncand; c = g2 / nt; r = full + (g2 - c * nt); }
+    }
+#endif
     const int qi = r / nbg, bg = r - qi * nbg;
     const int s = qslots[qi], pi = slot_phase[s], k = slot_k[s];
     const int b = bg * 16 + (threadIdx.x >> 2);
@@ -749,7 +767,7 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
         if (h->n_other) CREATE_CK(hipMemcpy(h->d_oslots, os.data(), os.size() * 4, hipMemcpyHostToDevice));
         const char* e = getenv("HSDDP_QUAD"); h->quad = !(e && e[0] == '0');
     }
-    CREATE_CK(hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int))); for (int q = 0; q < 4; q++) h->h_counters[q] = 0;
     CREATE_CK(hipDeviceSynchronize());
 #undef CREATE_CK
     *out = h; return HSDDP_OK;
@@ -945,7 +963,7 @@ static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, 
     Timed t(h, "k_eval");
     if (count) hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
     hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou, hist_of(h));
-    if (count) hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (count) { for (int q = 0; q < 4; q++) h->h_counters[q] = -1; hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream); }      // -1: "not delivered" (SYNC_COUNTERS)
 }
 static void launch_update_nominal(hsddp_handle* h, int mask) {
     Timed t(h, "k_update_nominal");
@@ -967,7 +985,8 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
     auto t0 = std::chrono::high_resolution_clock::now();
     auto elapsed = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t0).count(); };
     const bool budget = max_cputime_ms < 1e5f;
-    auto timeup = [&]() { if (!budget) return false; hipStreamSynchronize(h->stream); float e = elapsed(); return e > max_cputime_ms || fabsf(e - max_cputime_ms) <= 1e-6f; };
+    hipError_t sync_err = hipSuccess;      // every host decision below reads counters a synchronise has to deliver: a failed one ends the solve
+    auto timeup = [&]() { if (!budget) return false; if ((sync_err = hipStreamSynchronize(h->stream)) != hipSuccess) return true; float e = elapsed(); return e > max_cputime_ms || fabsf(e - max_cputime_ms) <= 1e-6f; };
     bool timed_out = false;
     // initial rollout (MultiPhaseDDP.cpp:238-241)
     launch_rollout(h, 0.0, o, MASK_NONE);
@@ -978,24 +997,24 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
         for (int iter_in = 1; iter_in <= opt->max_DDP_iter && !timed_out; iter_in++) {
             if (iter_in == 1 && iter_ou > 1) launch_cost(h, o, MASK_INNER);   // parameters changed: refresh costs
             launch_eval(h, EV_INNER_BEGIN, o, 0.0, false, iter_ou);
-            if (timeup()) { timed_out = true; break; }
+            if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
             launch_lq(h, o, MASK_INNER);
-            if (timeup()) { timed_out = true; break; }
+            if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
             launch_sweep(h, o, MASK_INNER, 0.0, 1, o.MS ? 1 : 0, 1.0, nullptr);      // (linear rollout only with multiple shooting, MultiPhaseDDP.cpp:326-329)
-            if (timeup()) { timed_out = true; break; }
+            if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
             launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
             // ---- line search (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:95-133): the step lengths 1, alpha, alpha^2, ... > 1e-3
             std::vector<double> steps; for (double e = 1.0; e > 1e-3; e *= opt->alpha) { steps.push_back(e); if (!(opt->alpha < 1.0) || steps.size() > 4096) break; }
             // the full step first, on its own: most searches end here, and it is the one whose trajectories are most likely to stay
             launch_rollout(h, steps[0], o, MASK_LS);
             launch_eval(h, EV_LS_TRIAL, o, steps[0], true, iter_ou);
-            hipStreamSynchronize(h->stream);
+            SYNC_COUNTERS();
             size_t next = 1;
             if (!(o.MS && h->probe_ok)) {      // single shooting through SRB / HKD phases hands its state over in memory: one trial per launch
                 while (h->h_counters[2] != 0 && next < steps.size()) {
                     launch_rollout(h, steps[next], o, MASK_LS);
                     launch_eval(h, EV_LS_TRIAL, o, steps[next], true, iter_ou);
-                    hipStreamSynchronize(h->stream); next++;
+                    SYNC_COUNTERS(); next++;
                 }
             }
             // every remaining candidate of the problems still searching in ONE launch (chunks of MAXCAND): candidates x problems x knots run
@@ -1013,16 +1032,17 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
                     Timed t(h, "k_eval");
                     hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
                     hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, h->sa, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters);
+                    for (int q = 0; q < 4; q++) h->h_counters[q] = -1;
                     hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 }
-                hipStreamSynchronize(h->stream);
+                SYNC_COUNTERS();
                 if (h->h_counters[3] != 0) launch_rollout(h, 0.0, o, MASK_COMMIT, true);      // problems that accepted a probe: their own step, for real
                 next += el.n;
             }
             launch_update_nominal(h, MASK_LS_OK);
             launch_eval(h, EV_POST_LS, o, 0.0, true, iter_ou);
-            if (timeup()) { timed_out = true; break; }
-            hipStreamSynchronize(h->stream);
+            if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
+            SYNC_COUNTERS();
             if (h->h_counters[0] == 0) break;
         }
         if (timed_out) break;
@@ -1031,7 +1051,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             Timed t(h, "k_update_params");
             hipLaunchKernelGGL(k_update_params, dim3(8, h->batch), dim3(256), 0, h->stream, h->d_ph, h->nph, o, h->d_st, h->d_do_update);
         }
-        hipStreamSynchronize(h->stream);
+        SYNC_COUNTERS();
         if (h->h_counters[1] == 0) break;
     }
     if (timed_out) launch_eval(h, EV_TIMEOUT, o, 0.0, false, 0);
