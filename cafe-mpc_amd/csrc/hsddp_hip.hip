@@ -87,6 +87,23 @@ template <bool WBM, class LDS> __device__ __forceinline__ void rollout_chain(LDS
 // slice c of the slot arrays - except candidate `writer` (the last of the search), which also writes the trajectories like an ordinary trial.
 constexpr int MAXCAND = 12;
 struct EpsList { double e[MAXCAND]; int n, writer, from_state; };
+// Probe launches: grid = candidates x units.  Workgroups go round-robin over the 8 XCDs (one L2 each); the candidates of a unit read the same
+// trajectories and differ in eps only.  Unit u lives on XCD u % 8 and its candidates occupy consecutive dispatch slots of that XCD, so one of them
+// brings the lines into that L2 and the others find them there (candidate-major order streamed the whole ensemble from HBM once per candidate:
+// probe launch of the quad kernel 11.4 -> 9.8 ms).  QUAD_CAND_MAJOR 1 = the old order.
+#ifndef QUAD_CAND_MAJOR
+#define QUAD_CAND_MAJOR 0
+#endif
+__device__ __forceinline__ void cand_unit(int per, int g, int& c, int& r) {
+#if QUAD_CAND_MAJOR
+    c = g / per; r = g - c * per;
+#else
+    const int ncand = gridDim.x / per;
+    const int full = (per >> 3) << 3;
+    if (g < full * ncand) { const int G = g / (8 * ncand), rem = g - G * 8 * ncand; c = rem >> 3; r = G * 8 + (rem & 7); }
+    else { const int nt = per - full, g2 = g - full * ncand; c = g2 / nt; r = full + (g2 - c * nt); }
+#endif
+}
 
 // LDS of the kernels instantiated WITHOUT the whole-body model (kinodynamic / single-rigid-body handles): 8 KB instead of 16 / 40 KB, so that
 // their small knots are not held to the whole-body kernels' two waves per SIMD
@@ -98,7 +115,7 @@ union RedLds { HkdLds h; SrbLds s; };
 template <bool WBM, class LDS> __device__ __forceinline__ void rollout_body(LDS& L, ROLL_ARGS) {
     PhaseC* ph = (PhaseC*)ph_;   // descriptors: constant memory, scalar loads
     const int per = batch * nlist;
-    const int c = blockIdx.x / per, r = blockIdx.x - c * per;
+    int c, r; cand_unit(per, blockIdx.x, c, r);
     const int b = r / nlist, si = r - b * nlist;
     if (masked_out(st[b], mask)) return;
     if (si == 0 && threadIdx.x == 0) atomicAdd(units, (unsigned long long)unit_knots);     // knots this launch rolls out (measurement only)
@@ -154,9 +171,6 @@ __global__ void __launch_bounds__(64) ROLL_HKD_ATTR k_rollout_hkd(ROLL_ARGS) { _
 
 // The whole-body running knots of the phases with shooting nodes on LANE QUADS (wb_quad.hpp): one lane per leg, sixteen problems of the same
 // (candidate, knot) per wave.  grid = candidates x knots of the list x ceil(batch / 16); qslots: the slots this kernel owns.
-#ifndef QUAD_CAND_MAJOR
-#define QUAD_CAND_MAJOR 0      // 1: the round-3a order (candidate slowest)
-#endif
 #ifndef QUAD_WPE
 #define QUAD_WPE 1      // waves per SIMD the quad kernel is compiled for (1: up to 512 registers, nothing in scratch; 2: 256 registers)
 #endif
@@ -166,20 +180,7 @@ k_rollout_quad(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, co
     PhaseC* ph = (PhaseC*)ph_;
     const int nbg = (batch + 15) >> 4;
     const int per = nq * nbg;
-    // Workgroups go round-robin over the 8 XCDs (one L2 each).  The candidates of a unit (16 problems x one knot) read the same trajectories
-    // and differ in eps only: unit u lives on XCD u % 8 and its candidates occupy consecutive dispatch slots of that XCD, so one of them brings
-    // the lines into that L2 and the others find them there (candidate-major order streamed the whole ensemble from HBM once per candidate).
-    const int ncand = gridDim.x / per;
-    int c, r;
-#if QUAD_CAND_MAJOR
-    c = blockIdx.x / per; r = blockIdx.x - c * per;
-#else
-    {
-        const int full = (per >> 3) << 3, g = blockIdx.x;
-        if (g < full * ncand) { const int G = g / (8 * ncand), rem = g - G * 8 * ncand; c = rem >> 3; r = G * 8 + (rem & 7); }
-        else { const int nt = per - full, g2 = g - full * ncand; c = g2 / nt; r = full + (g2 - c * nt); }
-    }
-#endif
+    int c, r; cand_unit(per, blockIdx.x, c, r);
     const int qi = r / nbg, bg = r - qi * nbg;
     const int s = qslots[qi], pi = slot_phase[s], k = slot_k[s];
     const int b = bg * 16 + (threadIdx.x >> 2);
