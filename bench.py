@@ -324,6 +324,7 @@ def main():
                            "parallelism": f"ensemble-sharded x{world}", "n_status_ok": int((res_all[:, 7] == 0).sum()),
                            "mean_ls_trials_per_iter": float(res_all[:, 5].sum() / max(iters_done, 1))},
                 "roofline": roof}
+        line["collectives"] = "rccl" if dist is not None else "none (single process)"
         line["per_rank"] = {"solve_ms": [round(float(v), 3) for v in per_rank[:, 0]], "iterations": [int(v) for v in per_rank[:, 1]], "ls_trials": [int(v) for v in per_rank[:, 2]],
                             "iter_imbalance": float(per_rank[:, 1].max() / max(per_rank[:, 1].mean(), 1.0)), "time_imbalance": float(per_rank[:, 0].max() / max(per_rank[:, 0].mean(), 1e-9))}
         if world == 1 and not args.no_cpu_baseline:

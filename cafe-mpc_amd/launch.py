@@ -74,8 +74,8 @@ def maybe_spawn(n_ranks, script, argv, require_gpus=True):
 def init_ranks(backend):
     """(rank, world, local_rank, dist or None).  backend: "nccl" (RCCL, one GPU per rank) or "gloo" (CPU rehearsal)."""
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
-        return 0, 1, local, None
+    if world == 1 and os.environ.get("HSDDP_FORCE_PROCESS_GROUP", "0") != "1":
+        return 0, 1, local, None      # (HSDDP_FORCE_PROCESS_GROUP=1: a one-rank group all the same - runs every RCCL call of the N > 1 path on a one-GPU box)
     import torch
     import torch.distributed as dist
     if backend == "nccl":

@@ -8,6 +8,7 @@ and single shooting through the single-rigid-body tail.  Every other test holds 
 """
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -854,3 +855,23 @@ def test_quad_and_one_wave_rollout_programs_agree(hip_lib, monkeypatch):
         for f in ("XBAR", "UBAR", "K", "Y"):
             a, b = sols[0].field(i, f), sols[1].field(i, f)
             assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(a).max()), (i, f, np.abs(a - b).max())
+
+
+@pytest.mark.gpu
+def test_rccl_calls_of_the_multi_gpu_bench_on_one_rank(tmp_path):
+    """the N > 1 path of bench.py (launcher env, RCCL process group on the rank's own device, barrier, all-gather of the 64-byte
+    result structs, max / sum / per-rank gathers) has no node to run on in this pool; every one of its RCCL calls runs here in a ONE-rank group
+    (HSDDP_FORCE_PROCESS_GROUP=1) started the way the driver starts N ranks."""
+    import subprocess, socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ, HSDDP_FORCE_PROCESS_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline", "--no-latency"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["collectives"] == "rccl" and line["n_gpus"] == 1
+    assert line["config"]["global_batch"] == 64 and line["config"]["n_status_ok"] == 64
+    assert len(line["per_rank"]["solve_ms"]) == 1 and line["per_rank"]["iterations"][0] == 64 * 2
+    assert line["value"] > 0
