@@ -15,6 +15,13 @@ from . import launch  # noqa: F401
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 HIP_LIB_PATH = _os.path.join(_HERE, "libhsddp_hip.so")
+# Measurement builds of the SAME HIP sources with other -D switches (make -C csrc variant NAME=x EXTRA=...; tools/ only): HSDDP_HIP_VARIANT=x selects
+# variants/libhsddp_hip_x.so.  Nothing but a build of csrc/hsddp_hip.hip can be named this way.
+_variant = _os.environ.get("HSDDP_HIP_VARIANT", "")
+if _variant:
+    if not _variant.replace("_", "").isalnum():
+        raise RuntimeError(f"HSDDP_HIP_VARIANT={_variant!r}: a plain name is expected")
+    HIP_LIB_PATH = _os.path.join(_HERE, "variants", f"libhsddp_hip_{_variant}.so")
 _lib = None
 
 

@@ -365,15 +365,18 @@ __global__ void __launch_bounds__(SW_NT, MINW_) NAME(const PhaseDev* ph_, int np
     if (threadIdx.x == 0) { st[blockIdx.x].dV_1 = S.c.dV1; st[blockIdx.x].dV_2 = S.c.dV2; } \
 }
 SWEEP_KERNEL(k_sweep, double, SW_SET_WB, SweepLds, SW_WB_WAVES)           // whole-body (+ SRB tail) phases
-SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)      // kinodynamic 24/24/0 phases, fp64
+#ifndef SW_HKD_WAVES
+#define SW_HKD_WAVES 3      // 51 KB of LDS -> three workgroups per CU; measured on config 5 in fp64 (k_sweep_hkd per launch): 2 waves per SIMD 161.8 ms, 3: 115.9
+#endif
+SWEEP_KERNEL(k_sweep_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_HKD_WAVES)      // kinodynamic 24/24/0 phases, fp64
 // fp32 handles (hsddp_create_ex): fp32 LQ records, every product of the Riccati step on v_mfma_f32_16x16x4_f32, an LDS block a third the size
 // (kinodynamic 24/24/0 and single-rigid-body phases only: SinglePhase.cpp:565-567, HKDModel.h:33-61)
 #ifndef SW_F32_WAVES
-#define SW_F32_WAVES 4
+#define SW_F32_WAVES 5      // measured on config 5 (k_sweep32 per launch): 3 waves per SIMD 98.3 ms (no spill), 4: 83.6, 5: 76.5 (96 registers), 6: 191
 #endif
 SWEEP_KERNEL(k_sweep32, float, SW_SET_HKD, SweepLds32, SW_F32_WAVES)
 LINEAR_KERNEL(k_linear, double, SW_SET_WB, SweepLds, SW_WB_WAVES)
-LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_MINB)
+LINEAR_KERNEL(k_linear_hkd, double, SW_SET_HKD, SweepLdsHkd, SW_HKD_WAVES)
 LINEAR_KERNEL(k_linear32, float, SW_SET_HKD, SweepLds32, SW_F32_WAVES)
 
 // receding-horizon shift of one phase (include/hsddp.h hsddp_warm_start_phase / hsddp_reconfigure): one workgroup per (problem, destination knot).
