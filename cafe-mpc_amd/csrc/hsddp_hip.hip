@@ -176,14 +176,18 @@ __global__ void __launch_bounds__(64) ROLL_HKD_ATTR k_rollout_hkd(ROLL_ARGS) { _
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QUAD_WPE, QUAD_WPE)))
 k_rollout_quad(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, const int* qslots, int nq, int nslots, int batch, ModelDev md, EpsList el, OptDev opt, const double* x0,
-               SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units) {
+               SlotArrays sa, const ProbState* st, int mask, int* fail, unsigned long long* units, const int* plist, int nlist) {
     PhaseC* ph = (PhaseC*)ph_;
-    const int nbg = (batch + 15) >> 4;
+    // plist / nlist: the problems this launch is for (null: all of the batch, `mask` picks).  A probe launch of a line search or a commit launch only
+    // concerns some problems; packed sixteen to a wave from the list the deciding kernel left behind, its waves are full whatever the share is
+    const int nprob = plist != nullptr ? nlist : batch;
+    const int nbg = (nprob + 15) >> 4;
     const int per = nq * nbg;
     int c, r; cand_unit(per, blockIdx.x, c, r);
     const int qi = r / nbg, bg = r - qi * nbg;
     const int s = qslots[qi], pi = slot_phase[s], k = slot_k[s];
-    const int b = bg * 16 + (threadIdx.x >> 2);
+    const int ix = bg * 16 + (threadIdx.x >> 2);
+    const int b = ix < nprob ? (plist != nullptr ? plist[ix] : ix) : batch;
     const bool active = b < batch && !masked_out(st[b < batch ? b : 0], mask);
     {   // knots this launch rolls out (measurement only): one atomic per wave
         const unsigned long long m = __ballot(active && (threadIdx.x & 3) == 0);
@@ -204,7 +208,8 @@ k_rollout_quad(const PhaseDev* ph_, const int* slot_phase, const int* slot_k, co
 // rolled out one after the other; the first accepted one ends the search.  ls_eps = the step whose trajectories the problem must hold
 // afterwards (the accepted one, else the last one tried: quirk vi); need_commit = those trajectories still have to be written (the
 // launch's writer was another candidate).
-__global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArrays sp, SlotArrays sa, EpsList el, int last_chunk, ProbState* st, OptDev opt, const int* fail, int* counters) {
+__global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArrays sp, SlotArrays sa, EpsList el, int last_chunk, ProbState* st, OptDev opt, const int* fail, int* counters,
+                                               int* ls_list, int* commit_list) {
     const int b = blockIdx.x, tid = threadIdx.x;
     ProbState& s = st[b];
     if (!s.ls_active) return;
@@ -247,8 +252,8 @@ __global__ void __launch_bounds__(64) k_ls_pick(int nslots, int batch, SlotArray
     }
     if (tid == 0) {
         s.need_commit = commit ? 1 : 0;
-        if (commit) atomicAdd(&counters[3], 1);
-        if (s.ls_active) atomicAdd(&counters[2], 1);
+        if (commit) commit_list[atomicAdd(&counters[3], 1)] = b;
+        if (s.ls_active) ls_list[atomicAdd(&counters[2], 1)] = b;
     }
 }
 
@@ -507,7 +512,7 @@ __device__ inline void hist_push(const HistDev& hd, int b, ProbState& s) {      
     s.info_tconstr = tc; s.info_pconstr = pc;      // get_terminal / get_path_constraint_violation() = buffer.back() (MultiPhaseDDP.h:81-83)
 }
 __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa, ProbState* st, OptDev opt, double eps, const int* fail, int* do_update,
-                                            int* counters, int iter_ou_host, HistDev hd) {
+                                            int* counters, int iter_ou_host, HistDev hd, int* ls_list) {
     const int b = blockIdx.x, tid = threadIdx.x;
     ProbState& s = st[b];
     __shared__ double rc[64], rd[64], rg[64], rh[64];
@@ -584,7 +589,7 @@ __global__ void __launch_bounds__(64) k_eval(int mode, int nslots, SlotArrays sa
         if (s.outer_active || s.inner_active) { s.status = 2; s.outer_active = 0; s.inner_active = 0; s.ls_active = 0; }
         break;
     }
-    if (counters) { if (s.inner_active) atomicAdd(&counters[0], 1); if (s.outer_active) atomicAdd(&counters[1], 1); if (s.ls_active) atomicAdd(&counters[2], 1); }
+    if (counters) { if (s.inner_active) atomicAdd(&counters[0], 1); if (s.outer_active) atomicAdd(&counters[1], 1); if (s.ls_active) { const int ix = atomicAdd(&counters[2], 1); if (ls_list) ls_list[ix] = b; } }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -599,7 +604,11 @@ struct hsddp_handle {
     PhaseDev* d_ph = nullptr;
     PhaseDev* d_ph_ss = nullptr;      // the same descriptors with every shooting flag cleared: what option.MS = false rolls out (MultiPhaseDDP.cpp:65-68)
     int *d_slot_phase = nullptr, *d_slot_k = nullptr, *d_fail = nullptr, *d_do_update = nullptr, *d_counters = nullptr, *d_success = nullptr;
+    int *d_ls_list = nullptr, *d_commit_list = nullptr;      // problems still searching / needing a commit rollout, in the order the deciding kernel met them (compact grids for the quad kernel)
     int *d_qslots = nullptr, *d_oslots = nullptr; int nq = 0, n_other = 0, other_knots = 0;      // slots of the lane-quad kernel (whole-body running knots of phases with shooting nodes) / the rest
+    bool ls_speculate = true;         // HSDDP_LS_SPECULATE=0: the full step of every line search is rolled out on its own (see hsddp_solve)
+    int ls_chunk = MAXCAND;           // candidates per probe launch (HSDDP_LS_CHUNK): problems that accept inside a chunk skip the later chunks, at one more launch + decision step per chunk
+    bool ls_probe_first = false;      // what the previous search of this handle suggests for the next one
     bool quad = true;                 // the lane-quad kernel takes its slots of every multiple-shooting rollout launch (HSDDP_QUAD=0: the one-wave programs everywhere)
     int* h_counters = nullptr;        // pinned
     SlotArrays sp{}; int sp_cands = 0;       // slot partials of the candidates of a batched line-search launch: [sp_cands][batch][nslots] (allocated on first use)
@@ -752,7 +761,7 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
     if (!rc) rc |= dalloc(h, &h->d_ph, h->nph_cap); if (!rc) rc |= dalloc(h, &h->d_ph_ss, h->nph_cap);
     if (!rc) rc |= dalloc(h, &h->d_slot_phase, h->slots_cap); if (!rc) rc |= dalloc(h, &h->d_slot_k, h->slots_cap);
     if (!rc) rc |= dalloc(h, &h->d_qslots, h->slots_cap); if (!rc) rc |= dalloc(h, &h->d_oslots, h->slots_cap);
-    if (!rc) rc |= dalloc(h, &h->d_fail, B * MAXCAND); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_success, B);
+    if (!rc) rc |= dalloc(h, &h->d_fail, B * MAXCAND); if (!rc) rc |= dalloc(h, &h->d_do_update, B); if (!rc) rc |= dalloc(h, &h->d_counters, 4); if (!rc) rc |= dalloc(h, &h->d_ls_list, B); if (!rc) rc |= dalloc(h, &h->d_commit_list, B); if (!rc) rc |= dalloc(h, &h->d_success, B);
     if (!rc) rc |= dalloc(h, &h->d_st, B); if (!rc) rc |= dalloc(h, &h->d_x0, B * h->ph[0].n); if (!rc) rc |= dalloc(h, &h->d_units, 8);
     if (!rc) rc |= dalloc(h, &h->sa.cost, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.dsq, B * h->slots_cap);
     if (!rc) rc |= dalloc(h, &h->sa.ming, B * h->slots_cap); if (!rc) rc |= dalloc(h, &h->sa.maxh, B * h->slots_cap);
@@ -770,6 +779,8 @@ int hsddp_create_ex(hsddp_handle_t** out, int n_phases, const hsddp_phase_desc_t
         if (h->nq) CREATE_CK(hipMemcpy(h->d_qslots, qs.data(), qs.size() * 4, hipMemcpyHostToDevice));
         if (h->n_other) CREATE_CK(hipMemcpy(h->d_oslots, os.data(), os.size() * 4, hipMemcpyHostToDevice));
         const char* e = getenv("HSDDP_QUAD"); h->quad = !(e && e[0] == '0');
+        const char* e2 = getenv("HSDDP_LS_SPECULATE"); h->ls_speculate = !(e2 && e2[0] == '0');
+        const char* e3 = getenv("HSDDP_LS_CHUNK"); if (e3 && atoi(e3) >= 1) h->ls_chunk = std::min(atoi(e3), MAXCAND);
     }
     CREATE_CK(hipHostMalloc((void**)&h->h_counters, 4 * sizeof(int))); for (int q = 0; q < 4; q++) h->h_counters[q] = 0;
     CREATE_CK(hipDeviceSynchronize());
@@ -916,13 +927,13 @@ int hsddp_set_control_knot(hsddp_handle_t* h, int phase, int k, const double* u)
 // ---- launch helpers
 enum { UNIT_ROLLOUT = 0, UNIT_LQ = 1, UNIT_SWEEP = 2, UNIT_PROBE = 3 };
 static HistDev hist_of(hsddp_handle* h) { return HistDev{h->d_hist, h->hist_cap}; }
-static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotArrays& sa, const OptDev& o, int mask, const char* name, int unit = UNIT_ROLLOUT) {
+static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotArrays& sa, const OptDev& o, int mask, const char* name, int unit = UNIT_ROLLOUT, const int* plist = nullptr, int nlist = 0) {
     Timed t(h, name);
     hipMemsetAsync(h->d_fail, 0, (size_t)h->batch * el.n * sizeof(int), h->stream);
     if (h->quad && o.MS && h->nq > 0) {      // whole-body running knots on lane quads, the rest (terminal knots, single-rigid-body tail) on the one-wave programs
-        const int nbg = (h->batch + 15) / 16;
+        const int nbg = ((plist ? nlist : h->batch) + 15) / 16;
         hipLaunchKernelGGL(k_rollout_quad, dim3((unsigned)((size_t)el.n * h->nq * nbg)), dim3(64), 0, h->stream, h->d_ph, h->d_slot_phase, h->d_slot_k, h->d_qslots, h->nq, h->nslots, h->batch,
-                           h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit);
+                           h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit, plist, nlist);
         if (h->n_other > 0)
             hipLaunchKernelGGL(k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->n_other)), dim3(64), 0, h->stream, h->d_ph, h->nph, h->d_slot_phase, h->d_slot_k,
                                h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit, h->d_oslots, h->n_other, h->other_knots);
@@ -931,9 +942,9 @@ static void launch_rollout_list(hsddp_handle* h, const EpsList& el, const SlotAr
     hipLaunchKernelGGL(h->has_hkd ? k_rollout_hkd : k_rollout, dim3((unsigned)((size_t)el.n * h->batch * h->nslots)), dim3(64), 0, h->stream, o.MS ? h->d_ph : h->d_ph_ss, h->nph, h->d_slot_phase, h->d_slot_k,
                        h->nslots, h->batch, h->md, el, o, h->d_x0, sa, h->d_st, mask, h->d_fail, h->d_units + unit, (const int*)nullptr, h->nslots, h->nslots - h->nph);
 }
-static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask, bool eps_from_state = false) {
+static void launch_rollout(hsddp_handle* h, double eps, const OptDev& o, int mask, bool eps_from_state = false, const int* plist = nullptr, int nlist = 0) {
     EpsList el{}; el.e[0] = eps; el.n = 1; el.writer = 0; el.from_state = eps_from_state ? 1 : 0;
-    launch_rollout_list(h, el, h->sa, o, mask, "k_rollout");
+    launch_rollout_list(h, el, h->sa, o, mask, "k_rollout", UNIT_ROLLOUT, plist, nlist);
     if (mask == MASK_NONE) h->cache_valid = true;     // masked launches only refresh problems whose cache was valid already
 }
 // slot arrays for the candidates of a probe launch, grown on demand (never inside an MPC tick once they exist)
@@ -966,7 +977,7 @@ static void launch_sweep(hsddp_handle* h, const OptDev& o, int mask, double reg,
 static void launch_eval(hsddp_handle* h, int mode, const OptDev& o, double eps, bool count, int iter_ou) {
     Timed t(h, "k_eval");
     if (count) hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
-    hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou, hist_of(h));
+    hipLaunchKernelGGL(k_eval, dim3(h->batch), dim3(64), 0, h->stream, mode, h->nslots, h->sa, h->d_st, o, eps, h->d_fail, h->d_do_update, count ? h->d_counters : nullptr, iter_ou, hist_of(h), h->d_ls_list);
     if (count) { for (int q = 0; q < 4; q++) h->h_counters[q] = -1; hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream); }      // -1: "not delivered" (SYNC_COUNTERS)
 }
 static void launch_update_nominal(hsddp_handle* h, int mask) {
@@ -992,6 +1003,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
     hipError_t sync_err = hipSuccess;      // every host decision below reads counters a synchronise has to deliver: a failed one ends the solve
     auto timeup = [&]() { if (!budget) return false; if ((sync_err = hipStreamSynchronize(h->stream)) != hipSuccess) return true; float e = elapsed(); return e > max_cputime_ms || fabsf(e - max_cputime_ms) <= 1e-6f; };
     bool timed_out = false;
+    int n_inner_est = h->batch;      // problems in the inner loop (upper bound until the first counted step): only steers where the full step of a line search is rolled out
     // initial rollout (MultiPhaseDDP.cpp:238-241)
     launch_rollout(h, 0.0, o, MASK_NONE);
     launch_update_nominal(h, MASK_NONE);
@@ -1006,14 +1018,29 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
             launch_sweep(h, o, MASK_INNER, 0.0, 1, o.MS ? 1 : 0, 1.0, nullptr);      // (linear rollout only with multiple shooting, MultiPhaseDDP.cpp:326-329)
             if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
-            launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
             // ---- line search (MultiPhaseDDP::line_search, MultiPhaseDDP.cpp:95-133): the step lengths 1, alpha, alpha^2, ... > 1e-3
             std::vector<double> steps; for (double e = 1.0; e > 1e-3; e *= opt->alpha) { steps.push_back(e); if (!(opt->alpha < 1.0) || steps.size() > 4096) break; }
-            // the full step first, on its own: most searches end here, and it is the one whose trajectories are most likely to stay
-            launch_rollout(h, steps[0], o, MASK_LS);
-            launch_eval(h, EV_LS_TRIAL, o, steps[0], true, iter_ou);
-            SYNC_COUNTERS();
-            size_t next = 1;
+            size_t next;
+            // Where does the full step go?  Normally it is rolled out on its own and WRITES its trajectories (most searches end there).  When the
+            // previous search of this handle saw most problems reject it (past convergence every search walks the whole ladder), its 11 KB per knot
+            // of trajectories and contact-solve cache are written only to be overwritten: it then rides as candidate 0 of the probe launch and a
+            // problem that does accept it gets the commit rollout every other accepted probe gets.  Same trials in the same order, same counts, same
+            // trajectories either way (test_line_search_speculation_is_invisible); only the schedule differs.
+            const bool probe_first = h->ls_speculate && h->ls_probe_first && o.MS && h->probe_ok;
+            int n_search0 = std::max(n_inner_est, 1);
+            if (probe_first) {
+                launch_eval(h, EV_PRE_LS, o, 0.0, true, iter_ou);
+                SYNC_COUNTERS();
+                n_search0 = std::max(h->h_counters[2], 1); next = 0;
+            } else {
+                launch_eval(h, EV_PRE_LS, o, 0.0, false, iter_ou);
+                // the full step first, on its own: most searches end here, and it is the one whose trajectories are most likely to stay
+                launch_rollout(h, steps[0], o, MASK_LS);
+                launch_eval(h, EV_LS_TRIAL, o, steps[0], true, iter_ou);
+                SYNC_COUNTERS();
+                next = 1;
+                h->ls_probe_first = 8 * (long long)(n_search0 - h->h_counters[2]) < n_search0;      // fewer than one problem in eight took the full step: speculate next time
+            }
             if (!(o.MS && h->probe_ok)) {      // single shooting through SRB / HKD phases hands its state over in memory: one trial per launch
                 while (h->h_counters[2] != 0 && next < steps.size()) {
                     launch_rollout(h, steps[next], o, MASK_LS);
@@ -1026,27 +1053,29 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             // quirk vi); k_ls_pick then walks the candidates in order per problem, and only problems that accepted an earlier candidate
             // need one more rollout of their own step (the commit)
             while (h->h_counters[2] != 0 && next < steps.size()) {
-                EpsList el{}; el.n = (int)std::min<size_t>(MAXCAND, steps.size() - next);
+                EpsList el{}; el.n = (int)std::min<size_t>(h->ls_chunk, steps.size() - next);
                 for (int c = 0; c < el.n; c++) el.e[c] = steps[next + c];
                 const bool last_chunk = next + el.n == steps.size();
                 el.writer = last_chunk ? el.n - 1 : -1; el.from_state = 0;
-                { int rc = ensure_probe_arrays(h, el.n); if (rc) return rc; }
-                launch_rollout_list(h, el, h->sp, o, MASK_LS, "k_ls_probe", UNIT_PROBE);
+                { int rc = ensure_probe_arrays(h, (int)std::min<size_t>(MAXCAND, steps.size())); if (rc) return rc; }      // (sized for the longest chunk of this ladder at once)
+                launch_rollout_list(h, el, h->sp, o, MASK_LS, "k_ls_probe", UNIT_PROBE, h->d_ls_list, h->h_counters[2]);      // (the counted step before left the list of problems still searching)
                 {
                     Timed t(h, "k_eval");
                     hipMemsetAsync(h->d_counters, 0, 4 * sizeof(int), h->stream);
-                    hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, h->sa, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters);
+                    hipLaunchKernelGGL(k_ls_pick, dim3(h->batch), dim3(64), 0, h->stream, h->nslots, h->batch, h->sp, h->sa, el, last_chunk ? 1 : 0, h->d_st, o, h->d_fail, h->d_counters, h->d_ls_list, h->d_commit_list);
                     for (int q = 0; q < 4; q++) h->h_counters[q] = -1;
                     hipMemcpyAsync(h->h_counters, h->d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 }
                 SYNC_COUNTERS();
-                if (h->h_counters[3] != 0) launch_rollout(h, 0.0, o, MASK_COMMIT, true);      // problems that accepted a probe: their own step, for real
+                if (h->h_counters[3] != 0) launch_rollout(h, 0.0, o, MASK_COMMIT, true, h->d_commit_list, h->h_counters[3]);      // problems that accepted a probe: their own step, for real
+                if (probe_first && next == 0) h->ls_probe_first = 8 * (long long)h->h_counters[3] < n_search0;      // one in eight or more needed a commit: back to writing the full step
                 next += el.n;
             }
             launch_update_nominal(h, MASK_LS_OK);
             launch_eval(h, EV_POST_LS, o, 0.0, true, iter_ou);
             if (timeup()) { if (sync_err != hipSuccess) HIPCK(sync_err); timed_out = true; break; }
             SYNC_COUNTERS();
+            n_inner_est = h->h_counters[0];
             if (h->h_counters[0] == 0) break;
         }
         if (timed_out) break;
@@ -1056,6 +1085,7 @@ int hsddp_solve(hsddp_handle_t* h, const hsddp_option_t* opt, float max_cputime_
             hipLaunchKernelGGL(k_update_params, dim3(8, h->batch), dim3(256), 0, h->stream, h->d_ph, h->nph, o, h->d_st, h->d_do_update);
         }
         SYNC_COUNTERS();
+        n_inner_est = h->h_counters[1];
         if (h->h_counters[1] == 0) break;
     }
     if (timed_out) launch_eval(h, EV_TIMEOUT, o, 0.0, false, 0);

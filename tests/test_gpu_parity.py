@@ -284,6 +284,40 @@ def test_fixed_work_past_convergence_line_search_counts(hip_lib, oracle_lib):
     pc.compare_solve(so, sg, len(phases))
 
 
+@pytest.mark.parametrize("case", ["past_convergence", "hard_start"])
+def test_line_search_speculation_is_invisible(hip_lib, case, monkeypatch):
+    """Where the full step of a line search is rolled out - on its own, writing its trajectories (default at first), or as candidate 0 of the
+    probe launch once the previous search saw most problems reject it (hsddp_solve) - is a schedule, not a result: a handle created with
+    HSDDP_LS_SPECULATE=0 and a speculating one end with bit-identical iterates, gains and counts, and the speculating one launched fewer
+    trajectory-writing rollouts.  hard_start: searches that accept in the middle of the ladder (commit rollouts after a speculative probe)."""
+    if case == "past_convergence":
+        phases = pkg.problems.wb_trot_problem(horizons=(20, 20, 20, 20)); x0 = pkg.problems.wb_ensemble_x0(6, 20241220 + 3)
+        opt = pkg.mhpc_ddp_setting(max_AL_iter=1, max_DDP_iter=14, cost_thresh=0.0)
+    else:
+        phases = pkg.problems.wb_stance_problem(horizon=50, ubar_mode="zero")
+        x0 = np.vstack([pkg.problems.wb_nominal_state()[None], pkg.problems.wb_ensemble_x0(5, 7)])
+        opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=6, cost_thresh=0.0)
+    solvers = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("HSDDP_LS_SPECULATE", flag)
+        s = pkg.MultiPhaseDDP(phases, batch=x0.shape[0])
+        s.set_initial_condition(x0); s.solve(opt)
+        solvers.append(s)
+    a, b = solvers
+    ia, ib = a.info_arrays(), b.info_arrays()
+    for key in ia:
+        if key != "solve_time_ms":
+            assert np.array_equal(ia[key], ib[key]), key
+    assert (ia["n_ls_iters"] > ia["n_iters"]).any()
+    for ph in range(len(phases)):
+        for f in ("XBAR", "UBAR", "K", "DU", "X", "U"):
+            assert np.array_equal(a.field(ph, f), b.field(ph, f)), (ph, f)
+    ka, kb = a.kernel_times(), b.kernel_times()
+    print("k_rollout launches without / with speculation:", ka["k_rollout"][1], kb["k_rollout"][1])
+    if case == "past_convergence":
+        assert kb["k_rollout"][1] < ka["k_rollout"][1], (ka["k_rollout"], kb["k_rollout"])       # the speculating handle really took the other schedule
+
+
 def test_zero_torque_start_line_search_and_regularisation(hip_lib, oracle_lib):
     """Ubar = 0 (testMHPCProblem.cpp:70-76): hard start that exercises multi-trial line searches and rejected steps."""
     phases = pkg.problems.wb_stance_problem(horizon=50, ubar_mode="zero")     # BASELINE config 1 literal
