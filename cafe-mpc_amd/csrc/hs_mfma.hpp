@@ -16,6 +16,9 @@ template <> struct MfmaT<double> {
     static HD int row(int lk, int r) { return lk + 4 * r; }
 #ifndef HS_HOST_EMU
     static HD acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products in 16 cycles (the 16 x 16 x 4 form takes 64; tools/probe/mfma_f64_4x4.hip measured
+    // both and printed the lane maps).  Block b = (l >> 2) & 3; lane l feeds A_b[i = l & 3][k = l >> 4] and B_b[k = l >> 4][j = l & 3], owns C_b[l >> 4][l & 3].
+    static HD double mma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 #endif
 };
 template <> struct MfmaT<float> {
@@ -23,6 +26,7 @@ template <> struct MfmaT<float> {
     static HD int row(int lk, int r) { return 4 * lk + r; }
 #ifndef HS_HOST_EMU
     static HD acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static HD float mma4(float, float, float c) { return c; }      // (no edge form in fp32: mfma_edge_tile is false for it)
 #endif
 };
 
@@ -47,6 +51,13 @@ template <class R = double> struct MTileT {
     }
 };
 using MTile = MTileT<double>;
+// EDGE TILES.  A tile with at most 4 rows (or 4 columns) inside the matrix - rows / columns 32..35 of the 36-wide whole-body blocks: 5 of the 9 tiles of a
+// 36 x 36 product - wastes three quarters of a 16 x 16 x 4 instruction.  In fp64 it is formed by the 4 x 4 x 4 x 4-block instruction instead: the strip's (up to)
+// four 4 x 4 blocks are the instruction's four blocks, same operands and operand reads, a quarter of the matrix-core time.
+#ifndef MFMA_EDGE4
+#define MFMA_EDGE4 1
+#endif
+template <class R> HD constexpr bool mfma_edge_tile(int M_, int N_, int i0, int j0) { return MFMA_EDGE4 && sizeof(R) == 8 && (M_ - i0 <= 4 || N_ - j0 <= 4); }
 template <int NTL, int KMAX, int KMAX2, class R>
 HD void mfma_tiles(int lane, const MTileT<R>* td) {
 #ifdef HS_HOST_EMU
@@ -71,33 +82,56 @@ HD void mfma_tiles(int lane, const MTileT<R>* td) {
     }
 #else
     const int li = lane & 15, lk = lane >> 4;
+    const int c4 = lane & 3, bk = (lane >> 2) & 3, r4 = lane >> 4;      // lane maps of the 4-block instruction (edge tiles)
     typename MfmaT<R>::acc c[NTL];
+    // per tile: (row, column) of the entries the lane feeds and owns.  Full tile: A row i0 + li, B column j0 + li, outputs (i0 + row(lk, r), j0 + li), r = 0..3.
+    // Edge tile with <= 4 rows: block bk covers columns j0 + 4 bk ..; with <= 4 columns: rows i0 + 4 bk ..; one output per lane (c[t][0]).
+#define HS_TILE_MAP(t) \
+        const bool edge = mfma_edge_tile<R>(td[t].M_, td[t].N_, td[t].i0, td[t].j0), rs = td[t].M_ - td[t].i0 <= 4; \
+        const int ia = edge ? td[t].i0 + (rs ? c4 : 4 * bk + c4) : td[t].i0 + li, jb = edge ? td[t].j0 + (rs ? 4 * bk + c4 : c4) : td[t].j0 + li; \
+        const int kl = edge ? r4 : lk; (void)kl; (void)ia; (void)jb;
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
-        const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0;
-            if (td[t].tmode != 0 && row < td[t].M_ && j < td[t].N_) c[t][r] += td[t].top(row, j); }
+        HS_TILE_MAP(t)
+        if (edge) {
+            const int row = td[t].i0 + (rs ? r4 : 4 * bk + r4), j = jb;
+            c[t][0] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0;
+            if (td[t].tmode != 0 && row < td[t].M_ && j < td[t].N_) c[t][0] += td[t].top(row, j);
+        } else {
+            const int j = td[t].j0 + li;
+            _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); c[t][r] = (td[t].Cin && row < td[t].M_ && j < td[t].N_) ? (td[t].TC ? td[t].Cin[j + td[t].ldcin * row] : td[t].Cin[row + td[t].ldcin * j]) : 0.0;
+                if (td[t].tmode != 0 && row < td[t].M_ && j < td[t].N_) c[t][r] += td[t].top(row, j); }
+        }
     }
     _Pragma("unroll") for (int kg = 0; kg < KMAX / 4; kg++) {
         _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K) {
-            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
+            HS_TILE_MAP(t)
+            const int i = ia, j = jb, k = 4 * kg + kl;
             const bool kv = k < td[t].K;
             const R a = (i < td[t].M_ && kv) ? (td[t].TA ? td[t].A[k + td[t].lda * i] : td[t].A[i + td[t].lda * k]) : 0.0;
             const R b = (j < td[t].N_ && kv) ? (td[t].TB ? td[t].B[j + td[t].ldb * k] : td[t].B[k + td[t].ldb * j]) : 0.0;
-            c[t] = MfmaT<R>::mma(a, b, c[t]);
+            if (edge) c[t][0] = MfmaT<R>::mma4(a, b, c[t][0]); else c[t] = MfmaT<R>::mma(a, b, c[t]);
         }
     }
     _Pragma("unroll") for (int kg = 0; kg < KMAX2 / 4; kg++) {
         _Pragma("unroll") for (int t = 0; t < NTL; t++) if (4 * kg < td[t].K2) {
-            const int i = td[t].i0 + li, j = td[t].j0 + li, k = 4 * kg + lk;
+            HS_TILE_MAP(t)
+            const int i = ia, j = jb, k = 4 * kg + kl;
             const R a = (i < td[t].M_) ? td[t].A2[k + td[t].lda2 * i] : 0.0;
             const R b = (j < td[t].N_) ? td[t].B2[k + td[t].ldb2 * j] : 0.0;
-            c[t] = MfmaT<R>::mma(a, b, c[t]);
+            if (edge) c[t][0] = MfmaT<R>::mma4(a, b, c[t][0]); else c[t] = MfmaT<R>::mma(a, b, c[t]);
         }
     }
     _Pragma("unroll") for (int t = 0; t < NTL; t++) {
-        const int j = td[t].j0 + li;
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
+        HS_TILE_MAP(t)
+        if (edge) {
+            const int row = td[t].i0 + (rs ? r4 : 4 * bk + r4), j = jb;
+            if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][0] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; }
+        } else {
+            const int j = td[t].j0 + li;
+            _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
+        }
     }
+#undef HS_TILE_MAP
 #endif
 }
 
