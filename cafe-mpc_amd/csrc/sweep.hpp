@@ -348,6 +348,14 @@ template <class R> HD const HS_GLOBAL R* rec_of(const PhaseDev& P);
 template <> HD const HS_GLOBAL double* rec_of<double>(const PhaseDev& P) { return P.rec; }
 template <> HD const HS_GLOBAL float* rec_of<float>(const PhaseDev& P) { return P.rec32; }
 
+// Dealing order of a tile list: the full 16 x 16 tiles first, the edge tiles (hs_mfma.hpp: a quarter of the matrix-core time) after them, so that a
+// round-robin deal hands every wave its share of both kinds.  E::edge(e) classifies list entry e; returns the ix-th entry in that order.
+template <class E> HD constexpr int deal_order(int n, int ix) {
+    int c = 0;
+    for (int e = 0; e < n; e++) if (!E::edge(e)) { if (c == ix) return e; c++; }
+    for (int e = 0; e < n; e++) if (E::edge(e)) { if (c == ix) return e; c++; }
+    return ix;
+}
 // MFMA tile lists of the two matrix phases of a Riccati step, dealt round-robin over the 4 waves.  W is a template
 // parameter so that every tile's kind and offsets are compile-time constants after unrolling.
 // DEAL 1 (SW_OVERLAP_LDLT): wave 0 forms what only Quu needs - the HB and lD tiles - and goes on to the Quu tiles inside the same phase; waves 1..3 share
@@ -365,7 +373,8 @@ HD void sweep_tiles1(SweepLdsT<N, M, PY, R>& S, int lane, R dt) {
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int ix = (W - 1) + 3 * q;
+        struct E1 { static constexpr bool edge(int e) { return e < t1 ? mfma_edge_tile<R>(N, N, 16 * (e % TN), 16 * (e / TN)) : mfma_edge_tile<R>(PY, N, 16 * ((e - t1) % TPd), 16 * ((e - t1) / TPd)); } };
+        const int ix = DEAL == 1 && W > 0 ? deal_order<E1>(nA, (W - 1) + 3 * q) : (W - 1) + 3 * q;
         const int t = DEAL == 1 ? (W == 0 ? (q < t2 - t1 ? t1 + q : t3 + (q - (t2 - t1))) : (ix < t1 ? ix : t2 + (ix - t1))) : (WBT && W == 0 && q == 4) ? 15 : W + 4 * q;
         // HA = H A = H(:, A0:) A_low (+ H [I, dt I] when the upper rows of A are the forward-Euler identities) ; HB = H(:, A0:) B_low
         if (t < t1) { td[q] = MTileT<R>{S.HA, LDN, nullptr, 0, 16 * (t % TN), 16 * (t / TN), N, N, S.H + LDN * A0, LDN, S.A, LDA, AR, false, nullptr, 0, nullptr, 0, 0};
@@ -389,7 +398,10 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int t = DEAL == 0 ? W + 4 * q : (W == 0 ? t2 + q : (W - 1) + 3 * q);
+        struct E2 { static constexpr bool edge(int e) {
+            if (e < t1) { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == e) return mfma_edge_tile<R>(N, N, 16 * ii, 16 * jj); c++; } return false; }
+            return mfma_edge_tile<R>(M, N, 16 * ((e - t1) % TM), 16 * ((e - t1) / TM)); } };
+        const int t = DEAL == 0 ? W + 4 * q : (W == 0 ? t2 + q : deal_order<E2>(t2, (W - 1) + 3 * q));
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
         // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
@@ -410,7 +422,8 @@ HD void sweep_tiles3(SweepLdsT<N, M, PY, R>& S, int lane) {
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
-        const int t = W + 4 * q;
+        struct E3 { static constexpr bool edge(int e) { return mfma_edge_tile<R>(N, N, 16 * (e % TN), 16 * (e / TN)); } };
+        const int t = deal_order<E3>(TN * TN, W + 4 * q);
         td[q] = MTileT<R>{S.H, LDN, S.H, LDN, 16 * (t % TN), 16 * (t / TN), N, N, S.Qux, LDM, S.K, LDM, M, true, nullptr, 0, nullptr, 0, 0};     // in place: H holds Qxx
     }
     mfma_tiles<(NTL > 0 ? NTL : 1), (M + 3) / 4 * 4, 0, R>(lane, td);
