@@ -39,6 +39,7 @@ template <class R = double> struct MTileT {
     const R* A2; int lda2; const R* B2; int ldb2; int K2;      // second product (always A2^T B2), K2 = 0: none
     bool TB = false;
     bool TC = false;      // C(i,j) (and Cin) at C[j + ldc*i] instead of C[i + ldc*j]
+    bool mirror = false;  // also store C(i,j) at the transposed position (an off-diagonal tile of a symmetric result whose lower partner is not formed)
     R dadd = 0.0;    // added to the entries C(i,i) of the tile's block (i.e. where the absolute row equals the absolute column)
     // structured operand [I, s I] folded in as an addend (whole-body A = [I, dt I; A21, A22]: the products run over the lower rows only):
     //   tmode 1 (H [I, s I]):    C(i,j) += j < tsplit ? T(i,j) : tscale * T(i, j - tsplit)
@@ -78,6 +79,7 @@ HD void mfma_tiles(int lane, const MTileT<R>* td) {
         for (int j = T.j0; j < T.j0 + 16 && j < T.N_; j++) for (int i = T.i0; i < T.i0 + 16 && i < T.M_; i++) {
             const R v = res[t][(i - T.i0) + 16 * (j - T.j0)] + ((i == j) ? T.dadd : 0.0);
             if (T.TC) T.Cout[j + T.ldc * i] = v; else T.Cout[i + T.ldc * j] = v;
+            if (T.mirror) { if (T.TC) T.Cout[i + T.ldc * j] = v; else T.Cout[j + T.ldc * i] = v; }
         }
     }
 #else
@@ -125,10 +127,12 @@ HD void mfma_tiles(int lane, const MTileT<R>* td) {
         HS_TILE_MAP(t)
         if (edge) {
             const int row = td[t].i0 + (rs ? r4 : 4 * bk + r4), j = jb;
-            if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][0] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; }
+            if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][0] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v;
+                if (td[t].mirror) { if (td[t].TC) td[t].Cout[row + td[t].ldc * j] = v; else td[t].Cout[j + td[t].ldc * row] = v; } }
         } else {
             const int j = td[t].j0 + li;
-            _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v; } }
+            _Pragma("unroll") for (int r = 0; r < 4; r++) { const int row = td[t].i0 + MfmaT<R>::row(lk, r); if (row < td[t].M_ && j < td[t].N_) { const R v = c[t][r] + ((row == j) ? td[t].dadd : 0.0); if (td[t].TC) td[t].Cout[j + td[t].ldc * row] = v; else td[t].Cout[row + td[t].ldc * j] = v;
+                if (td[t].mirror) { if (td[t].TC) td[t].Cout[row + td[t].ldc * j] = v; else td[t].Cout[j + td[t].ldc * row] = v; } } }
         }
     }
 #undef HS_TILE_MAP

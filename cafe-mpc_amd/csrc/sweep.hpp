@@ -405,7 +405,7 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
         // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
-        if (t < t1) { td[q] = MTileT<R>{S.H, LDN, nullptr, 0, 16 * bi, 16 * bj, N, N, S.A, LDA, S.HA + A0, LDN, AR, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg;     // into the H block (dead since phase 1); regularisation on Qxx as well: quirk x
+        if (t < t1) { td[q] = MTileT<R>{S.H, LDN, nullptr, 0, 16 * bi, 16 * bj, N, N, S.A, LDA, S.HA + A0, LDN, AR, true, S.C, LDM, S.lC, LDM, PY}; if (bi == bj) td[q].dadd = reg; else td[q].mirror = true;     // into the H block (dead since phase 1); regularisation on Qxx as well: quirk x; an upper tile also fills its mirror image (the symmetrisation of SinglePhase.cpp:376 for the tiles whose lower partner is not formed)
                       if (A0 > 0) { td[q].T = S.HA; td[q].ldt = LDN; td[q].tmode = 2; td[q].tsplit = A0; td[q].tscale = dt; } }
         else if (t < t2) td[q] = MTileT<R>{S.Qux, LDM, nullptr, 0, 16 * ((t - t1) % TM), 16 * ((t - t1) / TM), M, N, S.B, LDA, S.HA + A0, LDN, AR, true, S.D, LDM, S.lC, LDM, PY};
         else { td[q] = MTileT<R>{S.Quu, LDM, S.Quu, LDM, 16 * ((t - t2) % TM), 16 * ((t - t2) / TM), M, M, S.B, LDA, S.HB + A0, LDN, AR, true, S.D, LDM, S.lD, LDM, PY}; if ((t - t2) % TM == (t - t2) / TM) td[q].dadd = reg; }
@@ -525,12 +525,9 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
         // wave 0: the solves, LQ = -Quu_inv = -LDLT.solve(I) (SinglePhase.cpp:375) ; waves 1..3: symmetrise Qxx (SinglePhase.cpp:376)
         HS_PHASE_L(NT,
             if (tid < 64) ldlt_parts<M, LDM, R, 2>(tid, S.Quu, R(-1e-9), S.LQ, S.HB, reinterpret_cast<int*>(S.HB + M * M), &SWC.ok, S.HA, S.A);      // (HA, A: dead since phase 2)
-            else for (int e = tid - 64; e < N * N; e += NT - 64) {
-                const int i = e % N, j = e / N;
-                if (i < j) {     // inside a diagonal tile both halves were formed: average them; elsewhere mirror the upper tile
-                    const R s = (i / 16 == j / 16) ? (CM(S.H, i, j, LDN) + CM(S.H, j, i, LDN)) / 2 : CM(S.H, i, j, LDN);
-                    CM(S.H, i, j, LDN) = s; CM(S.H, j, i, LDN) = s;
-                }
+            else for (int e = tid - 64; e < TN * 256; e += NT - 64) {      // inside a diagonal tile both halves were formed: average them (the upper tiles mirrored themselves when they were stored)
+                const int i = 16 * (e >> 8) + (e & 15), j = 16 * (e >> 8) + ((e >> 4) & 15);
+                if (i < j && j < N) { const R s = (CM(S.H, i, j, LDN) + CM(S.H, j, i, LDN)) / 2; CM(S.H, i, j, LDN) = s; CM(S.H, j, i, LDN) = s; }
             })
         SW_STAMP(5)
 #else
