@@ -394,14 +394,14 @@ HD void sweep_tiles2(SweepLdsT<N, M, PY, R>& S, int lane, R reg, R dt) {
     // Qxx = lxx + A^T H A + C^T lyy C is symmetric: only the tiles on and above the block diagonal are formed (6 of 9 for the whole
     // body), the symmetrisation step of the reference (SinglePhase.cpp:376) fills the rest
     constexpr int t1 = TN * (TN + 1) / 2, t2 = t1 + TM * TN, t3 = t2 + TM * TM;
-    constexpr int NTL = DEAL == 0 ? (t3 - W + 3) / 4 : (W == 0 ? t3 - t2 : (t2 - (W - 1) + 2) / 3);
+    constexpr int NTL = DEAL == 0 ? (t3 - W + 3) / 4 : DEAL == 2 ? (t3 - t2 - W + 3) / 4 : (W == 0 ? t3 - t2 : (t2 - (W - 1) + 2) / 3);      // DEAL 2: the Quu tiles alone, round-robin
     if (NTL <= 0) return;
     MTileT<R> td[NTL > 0 ? NTL : 1];
     _Pragma("unroll") for (int q = 0; q < NTL; q++) {
         struct E2 { static constexpr bool edge(int e) {
             if (e < t1) { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == e) return mfma_edge_tile<R>(N, N, 16 * ii, 16 * jj); c++; } return false; }
             return mfma_edge_tile<R>(M, N, 16 * ((e - t1) % TM), 16 * ((e - t1) / TM)); } };
-        const int t = DEAL == 0 ? W + 4 * q : (W == 0 ? t2 + q : deal_order<E2>(t2, (W - 1) + 3 * q));
+        const int t = DEAL == 0 ? W + 4 * q : DEAL == 2 ? t2 + W + 4 * q : (W == 0 ? t2 + q : deal_order<E2>(t2, (W - 1) + 3 * q));
         int bi = 0, bj = 0;     // t-th pair (bi <= bj) in column order
         { int c = 0; for (int jj = 0; jj < TN; jj++) for (int ii = 0; ii <= jj; ii++) { if (c == t) { bi = ii; bj = jj; } c++; } }
         // A^T HA = A_low^T HA(A0:, :) (+ [I, dt I]^T HA(:A0, :)) ; B^T HA = B_low^T HA(A0:, :) ; B^T HB = B_low^T HB(A0:, :)
@@ -451,6 +451,9 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
     static_assert(NT == 256 && RL::rounds + 1 <= SW_PRE && N <= SW_N && 2 * N + M + PY <= NT && 64 + M <= NT - N - 1 - M && N <= 64 && M <= 64, "sweep limits");
     // lanes of the mat-vec chains that ride along with the tile phases (balance measured with the per-wave stamps, -DSW_PROF)
     constexpr bool WBS = (N == 36 && M == 12 && PY == 12);
+    // (measured and rejected for the 24 x 24 blocks of the kinodynamic model, where wave 0 carries 8 of the 12 phase-1 tiles on top of a 17 k-cycle factorisation: without the
+    // overlap the one-phase factorisation holds more live values than the 96 / 168-register occupancy points of those kernels allow - 529 spilled registers, k_sweep32 197 against 76 ms)
+    constexpr bool OVL = SW_OVERLAP_LDLT != 0;
     constexpr int GN0 = WBS ? 64 : 0, G0 = WBS ? 64 : NT - N, DV0 = WBS ? 64 + N : NT - N - 1, DU0 = WBS ? 64 + N + 1 : NT - N - 1 - M;
     constexpr int LDN = ST::LDN, LDM = ST::LDM, AR = ST::AR, LDA = ST::LDA, A0 = ST::A0;
     static_assert(sizeof(ST) <= sizeof(SS.raw), "the view fits the raw LDS block of its model set");
@@ -476,7 +479,13 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
         // round-robin over the 4 waves (whole body: 30 MFMAs per wave) ; Gnext = G + H Defect[k+1]
         HS_PHASE_L(NT, {
             const int w = tid >> 6, lane = tid & 63;
-#if SW_OVERLAP_LDLT
+            if constexpr (OVL && M > 12) {
+            // 24 x 24 control blocks (kinodynamic model): HB and Quu are four tiles each - on wave 0 alone they made it 9.9 k cycles against the others' 1.4-2.0 k
+            // (per-wave stamps).  Every phase-1 tile round-robin here, the Quu tiles over the four waves in a short phase of their own, then the factorisation beside
+            // the Qxx / Qux tiles as for the small blocks
+            switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane, dtR); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane, dtR); break;
+                         case 2: sweep_tiles1<2, N, M, PY, R>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane, dtR); }
+            } else if constexpr (OVL) {
             // wave 0: HB, lD - what only Quu needs - and, without a workgroup barrier (its own tiles), the Quu tiles themselves: Quu += B^T HB + D^T lD with the
             // regularisation on the diagonal; waves 1..3: HA, lC
             switch (w) { case 0: sweep_tiles1<0, N, M, PY, R, 1>(S, lane, dtR);
@@ -486,17 +495,22 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                                  sweep_tiles2<0, N, M, PY, R, 1>(S, lane, reg, dtR); break;
                          case 1: sweep_tiles1<1, N, M, PY, R, 1>(S, lane, dtR); break;
                          case 2: sweep_tiles1<2, N, M, PY, R, 1>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R, 1>(S, lane, dtR); }
-#else
+            } else {
             switch (w) { case 0: sweep_tiles1<0, N, M, PY, R>(S, lane, dtR); break; case 1: sweep_tiles1<1, N, M, PY, R>(S, lane, dtR); break;
                          case 2: sweep_tiles1<2, N, M, PY, R>(S, lane, dtR); break; default: sweep_tiles1<3, N, M, PY, R>(S, lane, dtR); }
-#endif
+            }
             // (whole body: the Gnext chain rides on wave 1 - per-wave stamps show it 2.5 k cycles ahead of wave 0, which carries three of the nine HA
             // tiles; the 24 / 12-row models deal two tiles to every wave and keep it on wave 0)
             if (tid >= GN0 && tid < GN0 + N) { const int i = tid - GN0; R s = S.G[i]; _Pragma("unroll 6") for (int j = 0; j < N; j++) s += CM(S.H, i, j, LDN) * S.def[j]; S.Gn[i] = s; }
             SW_WSTAMP(0)
         })
+        if constexpr (OVL && M > 12) {
+            HS_PHASE_L(NT, { const int w = tid >> 6, lane = tid & 63;
+                switch (w) { case 0: sweep_tiles2<0, N, M, PY, R, 2>(S, lane, reg, dtR); break; case 1: sweep_tiles2<1, N, M, PY, R, 2>(S, lane, reg, dtR); break;
+                             case 2: sweep_tiles2<2, N, M, PY, R, 2>(S, lane, reg, dtR); break; default: sweep_tiles2<3, N, M, PY, R, 2>(S, lane, reg, dtR); } })
+        }
         SW_STAMP(1)
-#if SW_OVERLAP_LDLT
+        if constexpr (OVL) {
         // phase 2, two jobs side by side.  Wave 0 (its Quu tiles are done: phase 1): Eigen's pivoted LDLT of (Quu - 1e-9 I), pivot order + factorisation
         // (SinglePhase.cpp:366-372).  Waves 1..3: Qxx - lxx =
         // A^T HA + C^T lC (into the H block), Qux = B^T HA + D^T lC, and the chains Qx += A^T Gn + C^T ly, Qu += B^T Gn + D^T ly.  The factorisation
@@ -530,7 +544,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                 if (i < j && j < N) { const R s = (CM(S.H, i, j, LDN) + CM(S.H, j, i, LDN)) / 2; CM(S.H, i, j, LDN) = s; CM(S.H, j, i, LDN) = s; }
             })
         SW_STAMP(5)
-#else
+        } else {
         // phase 2: Qxx - lxx = A^T HA + C^T lC (TN x TN, into the H block) ; Qux = B^T HA + D^T lC (TM x TN) ; Quu += B^T HB + D^T lD (TM x TM), round-robin ;
         // Qx += A^T Gn + C^T ly ; Qu += B^T Gn + D^T ly
         HS_PHASE_L(NT, {
@@ -570,7 +584,7 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
                 }
             })
         SW_STAMP(5)
-#endif
+        }
         if (!SWC.ok) return false;
         SW_STAMP(6)
         // K = -Quu_inv Qux on the matrix cores (TM x TN tiles over the waves) ; dU = -Quu_inv Qu on the last lanes   (SinglePhase.cpp:379-380)
@@ -588,18 +602,25 @@ HD bool riccati_phase(LDS& SS, const PhaseDev& P, int b, R reg) {
               switch (w) { case 0: sweep_tiles3<0, N, M, PY, R>(S, lane); break; case 1: sweep_tiles3<1, N, M, PY, R>(S, lane); break;
                            case 2: sweep_tiles3<2, N, M, PY, R>(S, lane); break; default: sweep_tiles3<3, N, M, PY, R>(S, lane); } }
             // (whole body: G, dV and the store of dU on wave 1 - two tiles and the shortest time in this phase; wave 3 carried them 1 k cycles behind)
-            if (tid >= G0 && tid < G0 + N) { const int i = tid - G0; R s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
+            if constexpr (!WBS && M > 12) {
+                // (24-row models: every wave carries one H tile, and the G chain - 24 dependent multiply-adds per lane - put wave 3 at 10.1 k cycles against 5-6 k:
+                // each row on a quad of lanes, the four partial sums added by DPP as in the linear rollout)
+                constexpr int CH = (M + 3) / 4;
+                SW_QUAD_ROWS(N, { _Pragma("unroll") for (int jj = 0; jj < CH; jj++) { const int t = part * CH + jj; if (t < M) partial += CM(S.Qux, t, o, LDM) * S.dU[t]; } },
+                             { const R s = S.Qx[o] + total; S.G[o] = s; gG[((size_t)b * (h + 1) + k) * N + o] = s; })
+            }
+            if ((WBS || M <= 12) && tid >= G0 && tid < G0 + N) { const int i = tid - G0; R s = S.Qx[i]; _Pragma("unroll") for (int t = 0; t < M; t++) s += CM(S.Qux, t, i, LDM) * S.dU[t]; S.G[i] = s; gG[((size_t)b * (h + 1) + k) * N + i] = s; }
             else if (tid == DV0) { R dVk = 0; _Pragma("unroll") for (int t = 0; t < M; t++) dVk -= S.Qu[t] * S.dU[t]; SWC.dV1 -= dVk; SWC.dV2 += dVk; }
             else if (tid >= DU0 && tid < DU0 + M) { const int a = tid - DU0; gdU[kk * M + a] = S.dU[a]; } SW_WSTAMP(3))
         SW_STAMP(7)
-#if SW_OVERLAP_LDLT
+        if constexpr (OVL) {
         // stores: the gains, and Qu / Quu / Qux as the reference keeps them (Quu carries the regularisation, SinglePhase.cpp:364-365) - by every wave alike,
         // so that the count of stores between the record prefetch and its commit is the same on all of them
         HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N); if (tid < M) gQu[kk * M + tid] = S.Qu[tid];
                    st_mat<NT>(tid, gQuu + kk * M * M, S.Quu, LDM, M, M); st_mat<NT>(tid, gQux + kk * M * N, S.Qux, LDM, M, N);)
-#else
+        } else {
         HS_PHASE_L(NT, st_mat<NT>(tid, gK + kk * M * N, S.K, LDM, M, N);)
-#endif
+        }
         SW_STAMP(8)
     }
     // G[0] += H[0] * Defect[0]   (SinglePhase.cpp:389)
