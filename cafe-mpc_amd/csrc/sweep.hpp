@@ -114,11 +114,11 @@ __device__ unsigned long long g_sw_prof[48];      // [0,16): phase stamps of thr
 // dependent multiply-add chain of a knot by four.
 #ifndef HS_HOST_EMU
 template <int CTRL> HD double dpp_quad(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 HD double quad_sum(double v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }     // quad_perm [1,0,3,2], then [2,3,0,1]
-template <int CTRL> HD float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> HD float dpp_quad(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
 HD float quad_sum(float v) { v += dpp_quad<0xB1>(v); v += dpp_quad<0x4E>(v); return v; }
 #endif
 // SW_QUAD_ROWS(CNT, PARTIAL, FINISH): for each output o < CNT, PARTIAL computes `partial` and `partial2` from (o, part = 0..3), FINISH

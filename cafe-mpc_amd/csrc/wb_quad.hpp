@@ -64,7 +64,7 @@ struct QH {      // host: the four lanes of ONE quad together
 };
 #else
 template <int CTRL> HD double q_dpp(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 struct QD {      // GPU: S = one lane's double; the quad's other lanes are reached by DPP quad_perm (every lane of a quad must be active)
