@@ -201,6 +201,33 @@ def mpc_tick_cpp_probe(ticks=24):
     return keep
 
 
+def host_boundary_probe(s, x0, opt, dt_resident):
+    """The C-ABI takes HOST buffers (include/hsddp.h: set_initial_condition, set_nominal) and hands host buffers back (get_info).  `value` is timed with the inputs
+    resident; this leg times the same solve on the warm handle INCLUDING the transfers, twice: (a) what the ensemble workload needs - x0 per problem, one shared nominal
+    trajectory per phase, the 64-byte result struct per problem back; (b) the worst case the boundary allows - a per-problem nominal trajectory for every phase as well."""
+    import time as _t
+    B = s.batch
+    shared = [(p["Xbar"], p["Ubar"]) for p in s.phases]
+    per_problem = [(np.ascontiguousarray(np.broadcast_to(np.asarray(xb)[None], (B,) + np.asarray(xb).shape)), np.ascontiguousarray(np.broadcast_to(np.asarray(ub)[None], (B,) + np.asarray(ub).shape)))
+                   for xb, ub in shared]
+    out = {}
+    for name, noms in (("shared_nominal", shared), ("per_problem_nominal", per_problem)):
+        t0 = _t.perf_counter()
+        s.set_initial_condition(x0)
+        for i, (xb, ub) in enumerate(noms):
+            s.set_nominal(i, xb, ub)
+        t1 = _t.perf_counter()
+        s.solve(opt)
+        t2 = _t.perf_counter()
+        info = s.info_arrays()
+        t3 = _t.perf_counter()
+        up = x0.nbytes + sum(np.asarray(xb).nbytes + np.asarray(ub).nbytes for xb, ub in noms)
+        out[name] = {"upload_MB": round(up / 1e6, 2), "upload_ms": round((t1 - t0) * 1e3, 2), "solve_ms": round((t2 - t1) * 1e3, 2), "download_ms": round((t3 - t2) * 1e3, 2),
+                     "download_MB": round(B * 64 / 1e6, 3), "value_inclusive": float(info["n_iters"].sum()) / (t3 - t0)}
+    out["note"] = ("same handle, same options as the timed solve (resident inputs: %.1f ms); the result download is Python-side struct unpacking more than PCIe" % (dt_resident * 1e3))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +360,8 @@ def main():
                 if args.hkd != "f32":          # (an fp32 handle is outside the fp64 tolerances: tests/test_gpu_parity.py holds it to its own)
                     line["parity_sample"] = parity_sample(s, so, len(s.phases))
                 so.close()
+        if world == 1 and not args.no_latency:
+            line["host_boundary"] = host_boundary_probe(s, x0, opt, dt)
         if world == 1 and not args.no_latency and not args.strong and not args.hkd:
             line["latency"] = latency_probe(pkg, args.steps)
             line["latency"]["mpc_tick"] = mpc_tick_probe(pkg)
