@@ -298,20 +298,26 @@ def test_line_search_speculation_is_invisible(hip_lib, case, monkeypatch):
         x0 = np.vstack([pkg.problems.wb_nominal_state()[None], pkg.problems.wb_ensemble_x0(5, 7)])
         opt = pkg.mhpc_ddp_setting(max_AL_iter=2, max_DDP_iter=6, cost_thresh=0.0)
     solvers = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("HSDDP_LS_SPECULATE", flag)
+    for flag, chunk in (("0", None), ("1", None), ("1", "3")):      # (third handle: the ladder in probe launches of three candidates - several chunks, the list of
+        monkeypatch.setenv("HSDDP_LS_SPECULATE", flag)               #  problems still searching rebuilt by every decision step)
+        if chunk is None:
+            monkeypatch.delenv("HSDDP_LS_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("HSDDP_LS_CHUNK", chunk)
         s = pkg.MultiPhaseDDP(phases, batch=x0.shape[0])
         s.set_initial_condition(x0); s.solve(opt)
         solvers.append(s)
-    a, b = solvers
-    ia, ib = a.info_arrays(), b.info_arrays()
-    for key in ia:
-        if key != "solve_time_ms":
-            assert np.array_equal(ia[key], ib[key]), key
+    a, b, c = solvers
+    ia = a.info_arrays()
     assert (ia["n_ls_iters"] > ia["n_iters"]).any()
-    for ph in range(len(phases)):
-        for f in ("XBAR", "UBAR", "K", "DU", "X", "U"):
-            assert np.array_equal(a.field(ph, f), b.field(ph, f)), (ph, f)
+    for other in (b, c):
+        io = other.info_arrays()
+        for key in ia:
+            assert np.array_equal(ia[key], io[key]), key
+        for ph in range(len(phases)):
+            for f in ("XBAR", "UBAR", "K", "DU", "X", "U"):
+                assert np.array_equal(a.field(ph, f), other.field(ph, f)), (ph, f)
+    assert c.kernel_times()["k_ls_probe"][1] > b.kernel_times()["k_ls_probe"][1]      # the chunked handle really launched more probe kernels
     ka, kb = a.kernel_times(), b.kernel_times()
     print("k_rollout launches without / with speculation:", ka["k_rollout"][1], kb["k_rollout"][1])
     if case == "past_convergence":
