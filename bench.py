@@ -329,9 +329,14 @@ def main():
             units = units_all.get(kname)
             per_launch_bytes = alg_bytes[kname] * (units / n if units else knots * B)
             ach = per_launch_bytes / (ms / n * 1e-3) / 1e9
-            per_kernel[kname] = {"avg_launch_ms": ms / n, "launches": n, "units_per_launch": (units / n if units else knots * B), "alg_bytes_per_unit": alg_bytes[kname],
+            upl = (units / n if units else knots * B)
+            tr = (traffic_all or {}).get("kernels", {}).get(kname)
+            if tr is not None:      # PMC bytes per knot (measured at batch 512 on these kernel sources) x the knots of one launch of THIS run = HBM bytes per launch, like `achieved`
+                tr = dict(tr, hbm_bytes_per_launch_raw=tr["hbm_bytes_per_knot_raw"] * upl, hbm_bytes_per_launch_fetch_x2=tr["hbm_bytes_per_knot_fetch_x2"] * upl,
+                          over_algorithmic_raw=tr["hbm_bytes_per_knot_raw"] / alg_bytes[kname], over_algorithmic_fetch_x2=tr["hbm_bytes_per_knot_fetch_x2"] / alg_bytes[kname])
+            per_kernel[kname] = {"avg_launch_ms": ms / n, "launches": n, "units_per_launch": upl, "alg_bytes_per_unit": alg_bytes[kname],
                                  "alg_bytes_per_launch": per_launch_bytes, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": (traffic_all or {}).get("kernels", {}).get(kname)}
+                                 "traffic": tr}
         roof = None
         if dom:
             d = per_kernel[dom]
