@@ -220,9 +220,11 @@ HD void ldlt_parts(int tid, const R* A, R diag_add, R* NI, R* Lw, int* iw, int* 
             _Pragma("unroll") for (int k = 0; k < M; k++) {
                 const unsigned long long at = __builtin_amdgcn_ballot_w64(tid >= k && gt <= k && k < ge);
                 const int big = (int)__builtin_ctzll(at);
-                const int ik = __builtin_amdgcn_readlane(ixp, k), gk = __builtin_amdgcn_readlane(gt, k), ek = __builtin_amdgcn_readlane(ge, k);
-                const int ib = __builtin_amdgcn_readlane(ixp, big), gb = __builtin_amdgcn_readlane(gt, big), eb = __builtin_amdgcn_readlane(ge, big);
-                ixp = (tid == k) ? ib : ((tid == big) ? ik : ixp); gt = (tid == k) ? gb : ((tid == big) ? gk : gt); ge = (tid == k) ? eb : ((tid == big) ? ek : ge);
+                if (big != k) {      // (uniform: a position that already holds an element of the current class stays as it is)
+                    const int ik = __builtin_amdgcn_readlane(ixp, k), gk = __builtin_amdgcn_readlane(gt, k), ek = __builtin_amdgcn_readlane(ge, k);
+                    const int ib = __builtin_amdgcn_readlane(ixp, big), gb = __builtin_amdgcn_readlane(gt, big), eb = __builtin_amdgcn_readlane(ge, big);
+                    ixp = (tid == k) ? ib : ((tid == big) ? ik : ixp); gt = (tid == k) ? gb : ((tid == big) ? gk : gt); ge = (tid == k) ? eb : ((tid == big) ? ek : ge);
+                }
             }
             if (act) iw[tid] = ixp;
         }
