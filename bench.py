@@ -198,6 +198,8 @@ def mpc_tick_cpp_probe(ticks=24):
     keep = {k: v for k, v in out.items() if k.endswith(("_mean", "_max")) or k in ("ticks", "budget_ms", "max_cputime_ms", "device_allocations_in_warm_ticks")}
     keep["config"] = "tests/cpp/mpc_loop.cpp on libhsddp_hip.so: shipped bound gait, 25 WB + 10 SRB knots, runtime limits (4 AL x 1 DDP), batch 1, max_cputime = 0.9 dt_mpc"
     keep["all_ticks_status_0"] = all(v == 0 for v in out["status"])
+    keep["total_ms_per_tick"] = [round(float(v), 3) for v in out["total_ms"]]      # (every tick, the first four are not in the statistics)
+    keep["iterations_per_tick"] = out["iters"]
     return keep
 
 
