@@ -9,6 +9,7 @@ import importlib
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 thr = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
+budget = sys.argv[4] if len(sys.argv) > 4 else "1"      # 0: solve without max_cputime (no time checkpoints)
 pkg = ge.load_package(); builder = importlib.import_module(pkg.__name__ + ".builder")
 tree = os.path.join(ROOT, "tests", "golden", "cafe_tree")
 with tempfile.TemporaryDirectory() as td:
@@ -18,7 +19,7 @@ with tempfile.TemporaryDirectory() as td:
     open(os.path.join(td, "opt.bin"), "wb").write(bytes(builder.load_ddp_setting(tree + "/MHPC/settings/ddp_setting.info")))
     worst = []
     for r in range(runs):
-        out = json.loads(subprocess.check_output([exe, tree, "bound", os.path.join(td, "opt.bin"), str(ticks)], timeout=300))
+        out = json.loads(subprocess.check_output([exe, tree, "bound", os.path.join(td, "opt.bin"), str(ticks), budget], timeout=300))
         tm = out["total_ms"]
         slow = [(i + 1, round(t, 2), out["iters"][i]) for i, t in enumerate(tm) if i >= 4 and t > thr]
         worst.append(max(tm[4:]))
